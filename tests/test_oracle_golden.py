@@ -1,0 +1,121 @@
+"""Pin the CPU oracle (oracle/dfa_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import dfa_oracle as O
+
+TOL = 1e-4  # north_star: logits within 1e-4 in fp32
+
+
+@pytest.mark.parametrize("tag", ["t321", "t64", "t7"])
+def test_cnn2d_forward_matches_reference(golden, tag):
+    sd, g = golden("cnn2d_eval")
+    x = np.swapaxes(g[f"{tag}.x_stored"], 1, 2)            # strided [B,T,F] view of stored [B,F,T]
+    logits, inter = O.cnn2d_forward(sd, x, return_intermediates=True)
+    assert logits.shape == g[f"{tag}.logits"].shape
+    np.testing.assert_allclose(logits, g[f"{tag}.logits"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(inter["embedding"], g[f"{tag}.embedding"], atol=1e-5, rtol=1e-5)
+
+
+def test_cnn2d_layers_match_reference(golden):
+    sd, g = golden("cnn2d_eval")
+    x = np.swapaxes(g["t16.x_stored"], 1, 2)
+    logits, inter = O.cnn2d_forward(sd, x, return_intermediates=True)
+    for k in ("a1", "a2", "a3"):
+        assert inter[k].shape == g[f"t16.{k}"].shape
+        np.testing.assert_allclose(inter[k], g[f"t16.{k}"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(logits, g["t16.logits"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["t321", "t64", "t7"])
+def test_cnn1d_forward_matches_reference(golden, tag):
+    sd, g = golden("cnn1d_eval")
+    x = np.swapaxes(g[f"{tag}.x_stored"], 1, 2)
+    logits = O.cnn1d_forward(sd, x)
+    np.testing.assert_allclose(logits, g[f"{tag}.logits"], atol=TOL, rtol=0)
+
+
+def test_cnn1d_layers_match_reference(golden):
+    sd, g = golden("cnn1d_eval")
+    x = np.swapaxes(g["t16.x_stored"], 1, 2)
+    _, inter = O.cnn1d_forward(sd, x, return_intermediates=True)
+    for k in ("h1", "h2", "h3"):
+        np.testing.assert_allclose(inter[k], g[f"t16.{k}"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["t321", "t64", "t70"])
+def test_cae_forward_matches_reference(golden, tag):
+    sd, g = golden("cae_eval")
+    x = g[f"{tag}.x"]
+    recon, latent = O.cae_forward(sd, x)
+    assert recon.shape == x.shape
+    np.testing.assert_allclose(latent, g[f"{tag}.latent"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(recon, g[f"{tag}.recon"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(O.per_sample_mse(recon, x), g[f"{tag}.mse"], rtol=1e-5)
+    T = x.shape[1]
+    if T % 16:
+        assert np.all(recon[:, 16 * (T // 16):, :] == 0)   # zero-padded tail rows (model_cae.py:116-119)
+
+
+def test_cae_fused_zscore_path(golden):
+    sd, g = golden("cae_eval")
+    raw = np.swapaxes(g["raw.x_stored"], 1, 2)
+    mean, std = O.normalizer_fit(list(raw))
+    np.testing.assert_allclose(mean, g["raw.mean"], atol=1e-6)
+    np.testing.assert_allclose(std, g["raw.std"], rtol=1e-6)
+    xz = O.normalizer_transform(raw, g["raw.mean"], g["raw.std"])
+    recon, _ = O.cae_forward(sd, xz)
+    np.testing.assert_allclose(recon, g["raw.recon"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(O.per_sample_mse(recon, xz), g["raw.mse"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("k", ["sep", "mix", "inv", "one", "tie", "rng"])
+def test_calculate_eer_known_answers(golden, k):
+    _, g = golden("host")
+    eer, thr = O.calculate_eer(g[f"eer.{k}.scores"].tolist(), g[f"eer.{k}.labels"].tolist())
+    assert (eer, thr) == tuple(g[f"eer.{k}.result"])
+    conf = O.confusion_at_threshold(g[f"eer.{k}.scores"], g[f"eer.{k}.labels"], thr)
+    assert tuple(float(c) for c in conf) == tuple(g[f"eer.{k}.confusion"])
+
+
+def test_eer_survey_values():
+    # SURVEY.md section 8(c)3, measured with the reference function
+    assert O.calculate_eer([.1, .2, .8, .9], [0, 0, 1, 1]) == (0.0, 0.2)
+    assert O.calculate_eer([.1, .4, .35, .8], [0, 0, 1, 1]) == (0.5, 0.35)
+    assert O.calculate_eer([.9, .8, .2, .1], [0, 0, 1, 1]) == (1.0, 0.2)
+    assert O.calculate_eer([.3, .6], [1, 1]) == (0.0, 0.0)
+    assert O.calculate_eer([.5] * 4, [0, 1, 0, 1]) == (0.5, 0.5)
+
+
+def test_normalizer_and_fusion(golden):
+    _, g = golden("host")
+    lens = g["norm.lens"]
+    feats = np.split(g["norm.feats"], np.cumsum(lens)[:-1])
+    mean, std = O.normalizer_fit(feats)
+    np.testing.assert_allclose(mean, g["norm.mean"], atol=1e-6)
+    np.testing.assert_allclose(std, g["norm.std"], rtol=1e-6)
+    np.testing.assert_allclose(O.normalizer_transform(feats[0], g["norm.mean"], g["norm.std"]), g["norm.t0"],
+                               rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(O.normalise_scores(g["fuse.sup"]), g["fuse.sup_norm"])
+    np.testing.assert_array_equal(O.normalise_scores(g["fuse.cae"]), g["fuse.cae_norm"])
+    np.testing.assert_array_equal(O.normalise_scores(np.full(5, 0.25)), g["fuse.const_norm"])
+    table, best_eer, best_alpha = O.hybrid_alpha_sweep(g["fuse.sup"], g["fuse.cae"], g["fuse.labels"].tolist())
+    np.testing.assert_array_equal(np.array(table), g["fuse.table"])
+    np.testing.assert_array_equal(O.ensemble_mean([g["fuse.sup"], g["fuse.cae"]]), g["fuse.ens_mean"])
+
+
+@pytest.mark.parametrize("tag,eps", [("ls0", 0.0), ("ls05", 0.05)])
+def test_bce_and_adamw_restatement(golden, tag, eps):
+    _, g = golden("cnn2d_train")
+    y = O.smooth_labels(g[f"{tag}.y"], eps) if eps > 0 else g[f"{tag}.y"]
+    loss, dz = O.bce_with_logits(g[f"{tag}.logits"], y)
+    np.testing.assert_allclose(loss, g[f"{tag}.loss"], rtol=2e-6)
+    np.testing.assert_allclose(dz, g[f"{tag}.dlogits"], rtol=1e-5, atol=1e-8)
+    # one AdamW step from the stored init + stored grads reproduces the reference's post-step params
+    for k in ("conv.0.weight", "conv.10.weight", "conv.6.bias", "classifier.weight"):
+        p0 = g["init.sd." + k]
+        if tag != "ls0":
+            continue
+        p1, _, _ = O.adamw_step(p0, g[f"{tag}.grad.{k}"], np.zeros_like(p0), np.zeros_like(p0), step=1)
+        np.testing.assert_allclose(p1, g[f"{tag}.after1.{k}"], rtol=2e-6, atol=2e-7)
