@@ -1,0 +1,134 @@
+"""ctypes binding of libdfa_hip.so (include/dfa_hip.h).  There is no CPU fallback: if the shared library is
+missing or a call fails, an exception is raised (ValueError for shape/dtype errors, RuntimeError otherwise,
+mirroring how the reference surfaces torch shape errors and its own ValueErrors)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdfa_hip.so")
+
+DFA_OK = 0
+E_BAD_SHAPE, E_BAD_DTYPE, E_NULL_PTR, E_NOT_PREPARED, E_HIP, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+DTYPE_F32, DTYPE_BF16 = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
+MODEL_CNN2D, MODEL_CNN1D, MODEL_CAE = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+
+_lib = None
+_lock = threading.Lock()
+
+# (name, restype, argtypes): every symbol include/dfa_hip.h declares
+SYMBOLS = [
+    ("dfa_version", C.c_int, []),
+    ("dfa_ctx_create", C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("dfa_ctx_destroy", C.c_int, [C.c_void_p]),
+    ("dfa_ctx_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dfa_last_error", C.c_char_p, [C.c_void_p]),
+    ("dfa_error_name", C.c_char_p, [C.c_int]),
+    ("dfa_cnn2d_set_params", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    ("dfa_cnn2d_prepare", C.c_int, [C.c_void_p, C.c_int]),
+    ("dfa_cnn2d_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("dfa_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("dfa_dominant_kernel", C.c_char_p, [C.c_int, C.c_int]),
+    ("dfa_ctx_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("dfa_ctx_timing_reset", C.c_int, [C.c_void_p]),
+    ("dfa_ctx_timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+]
+
+
+def load():
+    """dlopen libdfa_hip.so once and declare prototypes.  Raises RuntimeError when it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C deep-fake-audio-classifier_amd/csrc`).  dfa_amd has no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, res, args in SYMBOLS:
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(ctx_handle, code):
+    if code == DFA_OK:
+        return
+    lib = load()
+    msg = lib.dfa_last_error(ctx_handle).decode() if ctx_handle else ""
+    text = f"{lib.dfa_error_name(code).decode()}: {msg}"
+    if code in (E_BAD_SHAPE, E_BAD_DTYPE, E_UNSUPPORTED):
+        raise ValueError(text)
+    raise RuntimeError(text)
+
+
+class Context:
+    """One dfa_ctx per (process, device).  Holds the activation workspace (a torch uint8 tensor: storage only)."""
+    _by_device: dict = {}
+
+    def __init__(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError(f"dfa_amd runs on an AMD GPU (torch device 'cuda'), got device '{device}'. "
+                               "There is no CPU path.")
+        self.device = device
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        self.lib = load()
+        h = C.c_void_p()
+        code = self.lib.dfa_ctx_create(self.index, None, C.byref(h))
+        if code != DFA_OK:
+            raise RuntimeError(f"dfa_ctx_create(device={self.index}) failed: {self.lib.dfa_error_name(code).decode()}")
+        self.handle = h
+        self._ws = None
+
+    @classmethod
+    def get(cls, device) -> "Context":
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in cls._by_device:
+            cls._by_device[idx] = Context(torch.device("cuda", idx))
+        return cls._by_device[idx]
+
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.index).cuda_stream
+        check(self.handle, self.lib.dfa_ctx_set_stream(self.handle, C.c_void_p(s)))
+
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", self.index))
+        return self._ws
+
+    # ---- timing -----------------------------------------------------------------------------------------------
+    def timing(self, enable: bool):
+        check(self.handle, self.lib.dfa_ctx_timing_enable(self.handle, int(bool(enable))))
+
+    def timing_reset(self):
+        check(self.handle, self.lib.dfa_ctx_timing_reset(self.handle))
+
+    def timing_read(self, slot: int):
+        ms, n = C.c_float(), C.c_int()
+        check(self.handle, self.lib.dfa_ctx_timing_read(self.handle, slot, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def x_dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    raise ValueError(f"dfa_amd kernels take float32 or bfloat16 input, got {t.dtype}")
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,217 @@
+// api.hip -- the C ABI of libdfa_hip.so (include/dfa_hip.h): context lifecycle, weight preparation and the
+// eval-mode forward of the reference's CNN2D (src/model.py:33-42) as four stream-ordered launches:
+//   conv1 (+BN+ReLU+pool)  ->  block 2 MFMA conv (+BN+ReLU+pool)  ->  block 3 MFMA conv (+BN+ReLU+mean_T)  ->  linear.
+#include "dfa_internal.h"
+
+using namespace dfa;
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Cnn2dPlan {
+  int H1, H2;               // rows after pool 1 / pool 2
+  size_t a1_off, a2_off, emb_off, total;
+};
+
+Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
+  Cnn2dPlan p;
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  p.H1 = T / 2;
+  p.H2 = p.H1 / 2;
+  size_t off = 0;
+  p.a1_off = off;
+  off = align_up(off + (size_t)B * p.H1 * F * 32 * es, 256);
+  p.a2_off = off;
+  off = align_up(off + (size_t)B * p.H2 * F * 64 * es, 256);
+  p.emb_off = off;
+  off = align_up(off + (size_t)B * 128 * F * sizeof(float), 256);
+  p.total = off;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfa_version(void) { return DFA_VERSION; }
+
+const char* dfa_error_name(int code) {
+  switch (code) {
+    case DFA_OK: return "DFA_OK";
+    case DFA_E_BAD_SHAPE: return "DFA_E_BAD_SHAPE";
+    case DFA_E_BAD_DTYPE: return "DFA_E_BAD_DTYPE";
+    case DFA_E_NULL_PTR: return "DFA_E_NULL_PTR";
+    case DFA_E_NOT_PREPARED: return "DFA_E_NOT_PREPARED";
+    case DFA_E_HIP: return "DFA_E_HIP";
+    case DFA_E_WORKSPACE: return "DFA_E_WORKSPACE";
+    case DFA_E_UNSUPPORTED: return "DFA_E_UNSUPPORTED";
+    default: return "DFA_E_UNKNOWN";
+  }
+}
+
+int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out) {
+  if (!out) return DFA_E_NULL_PTR;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return DFA_E_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return DFA_E_HIP;
+  dfa_ctx* c = new dfa_ctx();
+  c->device = device_id;
+  c->stream = (hipStream_t)hip_stream;
+  *out = c;
+  return DFA_OK;
+}
+
+int dfa_ctx_destroy(dfa_ctx* ctx) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->cnn2d.packed) (void)hipFree(ctx->cnn2d.packed);
+  for (auto& t : ctx->slots) {
+    for (auto e : t.start) (void)hipEventDestroy(e);
+    for (auto e : t.stop) (void)hipEventDestroy(e);
+  }
+  delete ctx;
+  return DFA_OK;
+}
+
+int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  ctx->stream = (hipStream_t)hip_stream;
+  return DFA_OK;
+}
+
+const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  ctx->timing = enable != 0;
+  return DFA_OK;
+}
+
+int dfa_ctx_timing_reset(dfa_ctx* ctx) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  for (auto& t : ctx->slots) t.used = 0;
+  return DFA_OK;
+}
+
+int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count) {
+  if (!ctx || !total_ms || !count) return DFA_E_NULL_PTR;
+  if (slot < 0 || slot >= kMaxSlots) return fail(ctx, DFA_E_BAD_SHAPE, "timing slot %d out of range", slot);
+  SlotTimer& t = ctx->slots[slot];
+  float sum = 0.f;
+  for (int i = 0; i < t.used; ++i) {
+    DFA_HIP_CHECK(ctx, hipEventSynchronize(t.stop[i]));
+    float ms = 0.f;
+    DFA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t.start[i], t.stop[i]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *count = t.used;
+  return DFA_OK;
+}
+
+const char* dfa_dominant_kernel(int model, int precision) {
+  (void)precision;
+  if (model == DFA_MODEL_CNN2D) return "conv3x3_mfma_kernel";
+  return "";
+}
+
+/* ------------------------------------------------------------------------------------------------ CNN2D */
+int dfa_cnn2d_set_params(dfa_ctx* ctx, const float* const* device_params, int n, int in_features, int base_channels) {
+  if (!ctx || !device_params) return DFA_E_NULL_PTR;
+  if (n != DFA_CNN2D_NPARAMS) return fail(ctx, DFA_E_BAD_SHAPE, "cnn2d expects %d parameter pointers, got %d", DFA_CNN2D_NPARAMS, n);
+  if (base_channels != 32) return fail(ctx, DFA_E_UNSUPPORTED, "cnn2d HIP path is built for base_channels=32 (got %d)", base_channels);
+  if (in_features < 1) return fail(ctx, DFA_E_BAD_SHAPE, "in_features must be positive (got %d)", in_features);
+  for (int i = 0; i < n; ++i)
+    if (!device_params[i]) return fail(ctx, DFA_E_NULL_PTR, "cnn2d parameter %d is null", i);
+  for (int i = 0; i < n; ++i) ctx->cnn2d.p[i] = device_params[i];
+  ctx->cnn2d.in_features = in_features;
+  ctx->cnn2d.have_params = true;
+  ctx->cnn2d.prepared_prec = -1;
+  return DFA_OK;
+}
+
+int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn2dState& m = ctx->cnn2d;
+  if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_set_params has not been called");
+  if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // one allocation: w1[288] b1[32] | bias2[64] bias3[128] | wpack2 | wpack3   (sized for fp32, the larger mode)
+  const size_t w2_bytes = (size_t)64 * 32 * 9 * 4, w3_bytes = (size_t)128 * 64 * 9 * 4;
+  const size_t need = align_up((288 + 32 + 64 + 128) * sizeof(float), 256) + w2_bytes + w3_bytes;
+  if (!m.packed) {
+    DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, need));
+    m.packed_bytes = need;
+  }
+  char* base = (char*)m.packed;
+  m.w1 = (float*)base;
+  m.b1 = m.w1 + 288;
+  m.c2.bias = m.b1 + 32;
+  m.c3.bias = m.c2.bias + 64;
+  char* wp = base + align_up((288 + 32 + 64 + 128) * sizeof(float), 256);
+  m.c2.wpack = (uint4*)wp;
+  m.c3.wpack = (uint4*)(wp + w2_bytes);
+  const float* const* p = m.p;
+  DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
+  m.prepared_prec = precision;
+  return DFA_OK;
+}
+
+size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision) {
+  (void)ctx;
+  if (B < 1 || T < 1 || F < 1) return 0;
+  if (model == DFA_MODEL_CNN2D) return plan_cnn2d(B, T, F, precision).total;
+  return 0;
+}
+
+int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                      int64_t stride_f, float* logits, float* embedding, void* workspace, size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn2dState& m = ctx->cnn2d;
+  if (m.prepared_prec < 0) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_prepare has not been called since the last set_params");
+  if (!x || !logits || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, logits and workspace must be non-null");
+  if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
+  if (B < 1) return fail(ctx, DFA_E_BAD_SHAPE, "batch must be >= 1 (got %d)", B);
+  if (F != m.in_features)
+    return fail(ctx, DFA_E_BAD_SHAPE, "feature dim %d does not match in_features=%d of the classifier (src/model.py:31)", F, m.in_features);
+  if (T < 4) return fail(ctx, DFA_E_BAD_SHAPE, "T=%d is too short: two (2,1) average pools need T >= 4", T);
+  const int prec = m.prepared_prec;
+  const Cnn2dPlan pl = plan_cnn2d(B, T, F, prec);
+  if (workspace_bytes < pl.total)
+    return fail(ctx, DFA_E_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  if (((uintptr_t)workspace & 255) != 0) return fail(ctx, DFA_E_WORKSPACE, "workspace must be 256-byte aligned");
+  char* ws = (char*)workspace;
+  void* a1 = ws + pl.a1_off;
+  void* a2 = ws + pl.a2_off;
+  float* emb = embedding ? embedding : (float*)(ws + pl.emb_off);
+  hipStream_t s = ctx->stream;
+  {
+    ScopedSlot ts(ctx, 0);
+    DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.w1, m.b1, a1, prec, B, T, F, s));
+  }
+  {
+    ScopedSlot ts(ctx, 1);
+    ConvArgs a{};
+    a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;
+    a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1;
+    DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s));
+  }
+  {
+    ScopedSlot ts(ctx, 2);
+    ConvArgs a{};
+    a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
+    a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1;
+    DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s));
+  }
+  {
+    ScopedSlot ts(ctx, 3);
+    DFA_HIP_CHECK(ctx, launch_linear(emb, m.p[18], m.p[19], logits, B, 128 * F, s));
+  }
+  return DFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,19 @@
+// conv3x3_inst_cnn2d.hip -- the conv3x3_mfma instantiations used by the CNN2D forward (src/model.py:21-29,37).
+//   block 2: 32 -> 64 channels, AvgPool2d((2,1)) epilogue;   block 3: 64 -> 128 channels, mean-over-T epilogue.
+// Template arguments <T, CIN, NSL, MG, RP, MT, EPI, MINW>: see conv3x3_mfma.h.  MINW = waves/SIMD the register
+// allocator is asked to fit: the fp32 kernels keep 144/288 weight VGPRs per lane and run at one wave per SIMD.
+#include "dfa_internal.h"
+
+namespace dfa {
+
+hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s) {
+  if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_H2, 2>(a, s);
+  return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_POOL_H2, 1>(a, s);
+}
+
+hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s) {
+  if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_MEAN_T, 2>(a, s);
+  return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_MEAN_T, 1>(a, s);
+}
+
+}  // namespace dfa

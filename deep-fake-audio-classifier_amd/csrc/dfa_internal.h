@@ -1,0 +1,115 @@
+// dfa_internal.h -- context object and internal launch prototypes of libdfa_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dfa_hip.h"
+#include "conv3x3_mfma.h"
+
+namespace dfa {
+
+constexpr float kBnEps = 1e-5f;  // torch.nn.BatchNorm default (src/model.py:16)
+
+// ---- kernel timing slots (HIP events on the context's stream) -----------------------------------
+constexpr int kMaxSlots = 16;
+constexpr int kEventsPerSlot = 256;
+
+struct SlotTimer {
+  std::vector<hipEvent_t> start, stop;
+  int used = 0;
+};
+
+struct PackedConv {
+  uint4* wpack = nullptr;  // [COUT/32][9][CIN/KG][64]
+  float* bias = nullptr;   // [COUT]
+};
+
+struct Cnn2dState {
+  const float* p[DFA_CNN2D_NPARAMS] = {nullptr};
+  bool have_params = false;
+  int in_features = 0;
+  int prepared_prec = -1;
+  void* packed = nullptr;  // one device allocation holding everything below
+  size_t packed_bytes = 0;
+  float* w1 = nullptr;     // [32][9] folded
+  float* b1 = nullptr;     // [32]
+  PackedConv c2, c3;
+};
+
+}  // namespace dfa
+
+struct dfa_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  dfa::Cnn2dState cnn2d;
+  bool timing = false;
+  dfa::SlotTimer slots[dfa::kMaxSlots];
+};
+
+namespace dfa {
+
+inline int fail(dfa_ctx* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+inline int fail(dfa_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define DFA_HIP_CHECK(ctx, expr)                                                                  \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      return dfa::fail(ctx, DFA_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+// RAII-less helper: record start/stop events around a launch when ctx->timing is on
+struct ScopedSlot {
+  dfa_ctx* ctx;
+  int slot;
+  int idx;
+  ScopedSlot(dfa_ctx* c, int s) : ctx(c), slot(s), idx(-1) {
+    if (!ctx->timing) return;
+    SlotTimer& t = ctx->slots[slot];
+    if (t.used >= kEventsPerSlot) return;
+    if ((int)t.start.size() <= t.used) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      t.start.push_back(a);
+      t.stop.push_back(b);
+    }
+    idx = t.used++;
+    (void)hipEventRecord(t.start[idx], ctx->stream);
+  }
+  ~ScopedSlot() {
+    if (idx >= 0) (void)hipEventRecord(ctx->slots[slot].stop[idx], ctx->stream);
+  }
+};
+
+// ---- launch prototypes (one translation unit each, see Makefile) ---------------------------------
+// pack.hip
+hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                             const float* var, float* w1, float* b1, int cout, hipStream_t s);
+hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
+                                    const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
+                                    float* bias, hipStream_t s);
+// conv1.hip
+hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
+                        const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s);
+// linear.hip
+hipError_t launch_linear(const float* emb, const float* w, const float* bias, float* logits, int B, int K,
+                         hipStream_t s);
+// conv3x3_inst_*.hip
+hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s);
+
+}  // namespace dfa

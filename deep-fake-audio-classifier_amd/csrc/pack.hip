@@ -1,0 +1,86 @@
+// pack.hip -- weight preparation kernels: fold eval-mode BatchNorm into the preceding convolution and
+// lay the folded weights out in the order the forward kernels consume them.
+//
+// Folding (eval mode, src/predict.py:87): BN(conv(x)) = s*(conv_w*x) + (conv_b - mean)*s + beta with
+// s = gamma / sqrt(var + eps)  (torch.nn.BatchNorm2d, src/model.py:16,22,28; eps = 1e-5).
+#include "dfa_internal.h"
+
+namespace dfa {
+
+// block 1: w[32][1][3][3] -> w1[32][9] * s, b1[32]
+__global__ void fold_conv1_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                  const float* __restrict__ g, const float* __restrict__ beta,
+                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                  float* __restrict__ w1, float* __restrict__ b1, int cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout * 9) {
+    const int c = i / 9;
+    const float s = g[c] / sqrtf(var[c] + kBnEps);
+    w1[i] = w[i] * s;
+  }
+  if (i < cout) {
+    const float s = g[i] / sqrtf(var[i] + kBnEps);
+    b1[i] = (b[i] - mean[i]) * s + beta[i];
+  }
+}
+
+// 3x3 conv, w[COUT][CIN][3][3] -> wpack[COUT/32][9][CIN/KG][64 lanes][16 bytes].
+// Lane (r = lane&31, h = lane>>5), element j of its 16 bytes = s[co] * w[co = 32*slice + r][ci = KG*kg + (KG/2)*h + j][tap]
+// which is exactly the B operand of v_mfma_f32_32x32x16_bf16 (KG = 16) / four v_mfma_f32_32x32x2_f32 (KG = 8).
+template <typename T>
+__global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                         const float* __restrict__ g, const float* __restrict__ beta,
+                                         const float* __restrict__ mean, const float* __restrict__ var, int cin,
+                                         int cout, uint4* __restrict__ wpack, float* __restrict__ bias) {
+  constexpr int KG = 32 / (int)sizeof(T);
+  constexpr int EPL = KG / 2;  // elements per lane per k-group
+  const int nkg = cin / KG;
+  const int total = (cout / 32) * 9 * nkg * 64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout) {
+    const float s = g[i] / sqrtf(var[i] + kBnEps);
+    bias[i] = (b[i] - mean[i]) * s + beta[i];
+  }
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int kg = rest % nkg;
+  rest /= nkg;
+  const int tap = rest % 9;
+  const int slice = rest / 9;
+  const int co = slice * 32 + (lane & 31), hh = lane >> 5;
+  const float s = g[co] / sqrtf(var[co] + kBnEps);
+  T v[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int ci = KG * kg + EPL * hh + j;
+    v[j] = cvt_out<T>(w[((size_t)co * cin + ci) * 9 + tap] * s);
+  }
+  wpack[i] = *reinterpret_cast<const uint4*>(v);
+}
+
+hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                             const float* var, float* w1, float* b1, int cout, hipStream_t s) {
+  const int n = cout * 9;
+  hipLaunchKernelGGL(fold_conv1_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, b, g, beta, mean, var, w1, b1,
+                     cout);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
+                                    const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
+                                    float* bias, hipStream_t s) {
+  const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
+  int total = (cout / 32) * 9 * (cin / kg) * 64;
+  if (total < cout) total = cout;
+  dim3 grid((total + 255) / 256), block(256);
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL(fold_pack_conv3x3_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
+                       bias);
+  else
+    hipLaunchKernelGGL(fold_pack_conv3x3_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
+                       bias);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

@@ -1,0 +1,106 @@
+/*
+ * dfa_hip.h -- C ABI of libdfa_hip.so: the MI355X (gfx950) implementation of the LFCC-classifier
+ * hot path of kingdomseed/Deep-Fake-Audio-Classifier.
+ *
+ * The reference has no FFI of its own: its boundary for this path is the nn.Module surface of
+ * src/model.py:5-42 (CNN2D), src/model_cnn1d.py:5-46 (CNN1D), src/model_cae.py:20-125
+ * (ConvAutoencoder) plus the loss/optimiser calls of src/train.py:71-76,311-330.  Each entry point
+ * below names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named "device" is a HIP device pointer owned by the caller
+ *     (PyTorch-ROCm tensors are used for storage only);
+ *   - every function returns 0 (DFA_OK) or a negative DFA_E_* code; dfa_last_error() gives the text;
+ *   - a context is bound to one device and one HIP stream; calls enqueue work on that stream and
+ *     return without synchronising; a context is not thread-safe; one process per GPU for data parallel;
+ *   - no allocation on the hot path: activations live in a caller-provided workspace
+ *     (dfa_workspace_bytes), the library owns only the packed (BN-folded, MFMA-ordered) weights.
+ */
+#ifndef DFA_HIP_H
+#define DFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFA_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define DFA_OK 0
+#define DFA_E_BAD_SHAPE (-1)
+#define DFA_E_BAD_DTYPE (-2)
+#define DFA_E_NULL_PTR (-3)
+#define DFA_E_NOT_PREPARED (-4)
+#define DFA_E_HIP (-5)
+#define DFA_E_WORKSPACE (-6)
+#define DFA_E_UNSUPPORTED (-7)
+
+/* element types of the input tensor x */
+#define DFA_DTYPE_F32 0
+#define DFA_DTYPE_BF16 1
+
+/* arithmetic mode of the convolution stack (chosen at prepare time)
+ *   DFA_PREC_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) -- parity mode, logits within 1e-4
+ *   DFA_PREC_BF16 : bf16 storage of weights/activations, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- throughput mode */
+#define DFA_PREC_F32 0
+#define DFA_PREC_BF16 1
+
+/* model ids for dfa_workspace_bytes */
+#define DFA_MODEL_CNN2D 0
+#define DFA_MODEL_CNN1D 1
+#define DFA_MODEL_CAE 2
+
+typedef struct dfa_ctx dfa_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int dfa_version(void);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream */
+int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out);
+int dfa_ctx_destroy(dfa_ctx* ctx);
+int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
+const char* dfa_last_error(const dfa_ctx* ctx);
+const char* dfa_error_name(int code);
+
+/* ---- CNN2D (replaces CNN2D.__init__/forward, src/model.py:12-42) -------------------------------- */
+/* params: 20 device pointers (fp32) in state_dict order without num_batches_tracked:
+ *   conv.0.{weight,bias}, conv.1.{weight,bias,running_mean,running_var},
+ *   conv.5.{weight,bias}, conv.6.{weight,bias,running_mean,running_var},
+ *   conv.10.{weight,bias}, conv.11.{weight,bias,running_mean,running_var},
+ *   classifier.{weight,bias}
+ * The pointers are remembered (not copied); base_channels must be 32. */
+#define DFA_CNN2D_NPARAMS 20
+int dfa_cnn2d_set_params(dfa_ctx* ctx, const float* const* device_params, int n, int in_features,
+                         int base_channels);
+/* (re)build the BN-folded, MFMA-ordered weight images for eval-mode forward; call after any weight
+ * change (load_state_dict, optimiser step) or precision switch. */
+int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision);
+/* eval-mode forward: logits[b] = classifier(flatten(mean_T(conv(x[b]))))   (src/model.py:33-42)
+ *   x: device, element (b,t,f) at x + b*stride_b + t*stride_t + f*stride_f (strides in elements; the
+ *      reference harness passes the transposed view of the stored [B,F,T] tensor, src/predict.py:105);
+ *   logits: device float[B]; embedding: device float[B*128*F] in c*F+f order, or NULL
+ *      (src/model.py:40-41, src/embedding_anomaly.py:61);
+ *   workspace: device, >= dfa_workspace_bytes(ctx, DFA_MODEL_CNN2D, B, T, F, precision) bytes. */
+int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                      int64_t stride_t, int64_t stride_f, float* logits, float* embedding,
+                      void* workspace, size_t workspace_bytes);
+
+/* ---- shared ------------------------------------------------------------------------------------ */
+size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision);
+/* names of the device kernels a forward launches, for profile post-processing ("" when unknown) */
+const char* dfa_dominant_kernel(int model, int precision);
+/* ---- per-kernel timing (HIP events recorded on the context's stream around every launch) -------------
+ * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear.
+ * Enable, run forwards, then read (read synchronises on the recorded events; call it outside timed regions).
+ * At most 256 launches per slot are recorded between resets. */
+int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable);
+int dfa_ctx_timing_reset(dfa_ctx* ctx);
+int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFA_HIP_H */

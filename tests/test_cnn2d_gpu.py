@@ -1,0 +1,130 @@
+"""GPU parity tests for the CNN2D hot path: HIP kernels (through the C ABI) vs the CPU oracle and the committed
+golden vectors generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfa_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-4   # north_star: logits within 1e-4 in fp32
+
+
+def _model_from_sd(sd, precision="fp32"):
+    from dfa_amd.model import CNN2D
+    m = CNN2D(precision=precision)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return m.to("cuda").eval()
+
+
+def _ws_views(model, x, prec_bytes, B, T, F):
+    """channels-last activations left in the workspace by the last forward: a1 [B,T/2,F,32], a2 [B,T/4,F,64]."""
+    from dfa_amd import _lib
+    ctx = _lib.Context.get(x.device)
+    H1, H2 = T // 2, T // 4
+    n1 = B * H1 * F * 32 * prec_bytes
+    off2 = (n1 + 255) // 256 * 256
+    n2 = B * H2 * F * 64 * prec_bytes
+    dt = torch.float32 if prec_bytes == 4 else torch.bfloat16
+    ws = ctx._ws
+    a1 = ws[:n1].view(dt).view(B, H1, F, 32).float().cpu().numpy()
+    a2 = ws[off2:off2 + n2].view(dt).view(B, H2, F, 64).float().cpu().numpy()
+    return a1, a2
+
+
+@pytest.mark.parametrize("tag", ["t321", "t64", "t7"])
+def test_cnn2d_fp32_matches_golden(golden, tag):
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd)
+    stored = torch.from_numpy(g[f"{tag}.x_stored"]).to("cuda")
+    x = stored.transpose(1, 2)                                  # strided view (src/predict.py:105)
+    logits, emb = model(x, return_embedding=True)
+    assert logits.shape == g[f"{tag}.logits"].shape
+    np.testing.assert_allclose(logits.cpu().numpy(), g[f"{tag}.logits"], atol=TOL_F32, rtol=0)
+    np.testing.assert_allclose(emb.cpu().numpy(), g[f"{tag}.embedding"], atol=2e-5, rtol=1e-5)
+    # contiguous input gives the same answer
+    logits_c = model(x.contiguous())
+    np.testing.assert_allclose(logits_c.cpu().numpy(), logits.cpu().numpy(), atol=1e-6, rtol=0)
+
+
+def test_cnn2d_fp32_layers_match_golden(golden):
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd)
+    x = torch.from_numpy(g["t16.x_stored"]).to("cuda").transpose(1, 2)
+    logits = model(x)
+    a1, a2 = _ws_views(model, x, 4, 1, 16, 180)
+    np.testing.assert_allclose(a1.transpose(0, 3, 1, 2), g["t16.a1"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(a2.transpose(0, 3, 1, 2), g["t16.a2"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["t16.logits"], atol=TOL_F32, rtol=0)
+
+
+@pytest.mark.parametrize("B,T", [(1, 321), (5, 33), (2, 4), (3, 130)])
+def test_cnn2d_fp32_matches_oracle_random_shapes(golden, B, T):
+    sd, _ = golden("cnn2d_eval")
+    model = _model_from_sd(sd)
+    g = torch.Generator().manual_seed(100 + B * 1000 + T)
+    stored = torch.randn(B, 180, T, generator=g) * 3.2 - 0.07
+    want, inter = O.cnn2d_forward(sd, stored.numpy().swapaxes(1, 2), return_intermediates=True)
+    logits, emb = model(stored.to("cuda").transpose(1, 2), return_embedding=True)
+    np.testing.assert_allclose(emb.cpu().numpy(), inter["embedding"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(logits.cpu().numpy(), want, atol=TOL_F32, rtol=0)
+
+
+def test_cnn2d_other_in_features():
+    """F is a runtime dimension (strips of 32 columns with a ragged tail): try F=40 and F=65."""
+    from dfa_amd.model import CNN2D
+    for F in (40, 65):
+        torch.manual_seed(F)
+        m = CNN2D(in_features=F).to("cuda").eval()
+        with torch.no_grad():
+            m.classifier.weight.mul_(30.0)
+        sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+        x = torch.randn(2, 21, F)
+        want = O.cnn2d_forward(sd, x.numpy())
+        got = m(x.to("cuda")).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=TOL_F32, rtol=0)
+
+
+def test_cnn2d_bf16_mode_close_and_rank_preserving(golden):
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd, precision="bf16")
+    stored = torch.from_numpy(g["t321.x_stored"]).to("cuda")
+    want = g["t321.logits"]
+    got_f32in = model(stored.transpose(1, 2)).cpu().numpy()
+    got_bf16in = model(stored.to(torch.bfloat16).transpose(1, 2)).cpu().numpy()
+    # bf16 storage / fp32 accumulate: tolerance 2e-2 relative to |logit| ~ 3 (not the 1e-4 parity mode)
+    np.testing.assert_allclose(got_f32in, want, atol=0.06, rtol=0)
+    np.testing.assert_allclose(got_bf16in, want, atol=0.10, rtol=0)
+
+
+def test_cnn2d_batch_independence_full_size(golden):
+    """BASELINE configs[1] shape [256,321,180]: every utterance's logit must equal the logit it gets in a batch of
+    its own (eval mode has no cross-sample op) -- a size-independent property checked at the full benchmark size."""
+    sd, _ = golden("cnn2d_eval")
+    model = _model_from_sd(sd)
+    g = torch.Generator().manual_seed(7)
+    stored = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to("cuda")
+    x = stored.transpose(1, 2)
+    full = model(x).cpu().numpy()
+    for idx in (0, 1, 100, 255):
+        one = model(x[idx:idx + 1]).cpu().numpy()
+        np.testing.assert_allclose(one, full[idx:idx + 1], atol=1e-6, rtol=0)
+    # and a few against the oracle
+    want = O.cnn2d_forward(sd, stored[:3].cpu().numpy().swapaxes(1, 2))
+    np.testing.assert_allclose(full[:3], want, atol=TOL_F32, rtol=0)
+
+
+def test_cnn2d_error_behaviour(golden):
+    sd, _ = golden("cnn2d_eval")
+    model = _model_from_sd(sd)
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 321, 100, device="cuda"))          # F != in_features
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 3, 180, device="cuda"))            # T too short for two pools
+    with pytest.raises(ValueError):
+        model(torch.zeros(321, 180, device="cuda"))             # not (B,T,F)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 321, 180))                          # CPU input: no CPU path
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 321, 180, device="cuda", dtype=torch.float16))
