@@ -119,3 +119,21 @@ def test_bce_and_adamw_restatement(golden, tag, eps):
             continue
         p1, _, _ = O.adamw_step(p0, g[f"{tag}.grad.{k}"], np.zeros_like(p0), np.zeros_like(p0), step=1)
         np.testing.assert_allclose(p1, g[f"{tag}.after1.{k}"], rtol=2e-6, atol=2e-7)
+
+
+def test_torch_ref_matches_reference(golden):
+    """The plain-PyTorch restatement (oracle/torch_ref.py) is pinned against the same golden vectors."""
+    import torch
+    from oracle import torch_ref as R
+    sd, g = golden("cnn2d_eval")
+    x = torch.from_numpy(g["t321.x_stored"]).transpose(1, 2)
+    logits, emb = R.cnn2d_forward(sd, x, return_embedding=True)
+    np.testing.assert_allclose(logits.numpy(), g["t321.logits"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(emb.numpy(), g["t321.embedding"], atol=1e-5, rtol=1e-5)
+    sd, g = golden("cnn1d_eval")
+    x = torch.from_numpy(g["t64.x_stored"]).transpose(1, 2)
+    np.testing.assert_allclose(R.cnn1d_forward(sd, x).numpy(), g["t64.logits"], atol=TOL, rtol=0)
+    sd, g = golden("cae_eval")
+    recon, latent = R.cae_forward(sd, torch.from_numpy(g["t321.x"]))
+    np.testing.assert_allclose(recon.numpy(), g["t321.recon"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(latent.numpy(), g["t321.latent"], atol=2e-5, rtol=1e-5)
