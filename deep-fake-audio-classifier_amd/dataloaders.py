@@ -1,0 +1,78 @@
+"""Loaders -- counterpart of src/dataloaders.py:8-59 (same function names, arguments and defaults).
+
+`make_loader` / `create_dataloaders` return ordinary torch DataLoaders over `AudioDeepfakeDataset`, so reference
+scripts keep working.  `FlatBatcher` is the ingest path sized for the GPU: one contiguous (optionally pinned) tensor,
+batches are slices, host->device copies are asynchronous on a side stream and double-buffered.
+"""
+from __future__ import annotations
+
+import torch
+from torch.utils.data import DataLoader
+
+from . import dataset as ds
+
+
+def create_dataloaders(train_features_path, train_labels_path, dev_features_path, dev_labels_path,
+                       test_features_path, batch_size=32, num_workers=2):
+    """(train_loader [shuffled], dev_loader, test_loader [features only]) -- src/dataloaders.py:8-52."""
+    train = ds.AudioDeepfakeDataset(train_features_path, train_labels_path)
+    dev = ds.AudioDeepfakeDataset(dev_features_path, dev_labels_path)
+    test = ds.AudioDeepfakeDataset(test_features_path, None)
+    kw = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=True)
+    return (DataLoader(train, shuffle=True, **kw), DataLoader(dev, shuffle=False, **kw),
+            DataLoader(test, shuffle=False, **kw))
+
+
+def make_loader(features_path, labels_path, batch_size=32, num_workers=2, shuffle=False):
+    """src/dataloaders.py:55-59."""
+    return DataLoader(ds.AudioDeepfakeDataset(features_path, labels_path), batch_size=batch_size, shuffle=shuffle,
+                      num_workers=num_workers)
+
+
+class FlatBatcher:
+    """Iterate (features [b,180,321] on `device`, labels [b] on `device` or None) over a stacked dataset.
+
+    rank/world shard the utterance range contiguously (rank r gets [r*ceil(N/world), ...)): the data-parallel
+    inference partition of SURVEY.md section 8(e); order inside a shard is preserved so host code can concatenate.
+    """
+
+    def __init__(self, features: torch.Tensor, labels: torch.Tensor | None, batch_size: int, device="cuda",
+                 rank: int = 0, world: int = 1, dtype: torch.dtype | None = None):
+        n = features.shape[0]
+        per = -(-n // world)
+        self.lo, self.hi = min(rank * per, n), min((rank + 1) * per, n)
+        self.features, self.labels = features, labels
+        self.batch_size, self.device, self.dtype = batch_size, torch.device(device), dtype
+
+    def __len__(self):
+        return -(-(self.hi - self.lo) // self.batch_size)
+
+    def _put(self, lo, hi, stream):
+        with torch.cuda.stream(stream):
+            f = self.features[lo:hi].to(self.device, non_blocking=True)
+            if self.dtype is not None:
+                f = f.to(self.dtype)
+            l = None if self.labels is None else self.labels[lo:hi].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return f, l, ev
+
+    def __iter__(self):
+        if self.device.type != "cuda":
+            for lo in range(self.lo, self.hi, self.batch_size):
+                hi = min(lo + self.batch_size, self.hi)
+                yield self.features[lo:hi], (None if self.labels is None else self.labels[lo:hi])
+            return
+        copy_stream = torch.cuda.Stream(self.device)
+        starts = list(range(self.lo, self.hi, self.batch_size))
+        nxt = self._put(starts[0], min(starts[0] + self.batch_size, self.hi), copy_stream) if starts else None
+        for i, lo in enumerate(starts):
+            f, l, ev = nxt
+            if i + 1 < len(starts):
+                nlo = starts[i + 1]
+                nxt = self._put(nlo, min(nlo + self.batch_size, self.hi), copy_stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            f.record_stream(torch.cuda.current_stream(self.device))
+            if l is not None:
+                l.record_stream(torch.cuda.current_stream(self.device))
+            yield f, l

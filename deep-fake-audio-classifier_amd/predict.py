@@ -1,0 +1,98 @@
+"""Checkpoint -> prediction.pkl -- counterpart of src/predict.py (same CLI flags, same output schema: DataFrame
+{uttid, predictions} with Python-float scores, sigmoid applied by default), with the forward on the MI355X HIP path.
+
+    python -m dfa_amd.predict --features features.pkl --checkpoint cnn2d_best.pt --model cnn2d --out prediction.pkl
+"""
+from __future__ import annotations
+
+import argparse
+
+import pandas as pd
+import torch
+
+from .model import CNN2D
+
+
+def build_model(name: str, in_features: int = 180, dropout: float = 0.3, precision: str = "fp32"):
+    if name == "cnn2d":
+        return CNN2D(in_features=in_features, dropout=dropout, precision=precision)
+    if name == "cnn1d":
+        from .model_cnn1d import CNN1D
+        return CNN1D(in_features=in_features, dropout=dropout)
+    raise ValueError(f"unknown model {name!r} (choices: cnn2d, cnn1d)")
+
+
+def load_weights(model, checkpoint_path: str, device="cuda"):
+    """Accept the reference's checkpoint dict {"model_state": ...} or a bare state_dict (src/predict.py:78-85)."""
+    try:
+        ckpt = torch.load(checkpoint_path, map_location=device, weights_only=True)
+    except TypeError:
+        ckpt = torch.load(checkpoint_path, map_location=device)
+    state = ckpt["model_state"] if isinstance(ckpt, dict) and "model_state" in ckpt else ckpt
+    model.load_state_dict(state)
+    return model
+
+
+@torch.no_grad()
+def predict_scores(model, features: torch.Tensor, batch_size: int = 32, device="cuda", apply_sigmoid: bool = True,
+                   swap_tf: bool = True, rank: int = 0, world: int = 1, input_dtype=None) -> torch.Tensor:
+    """Scores for a stacked [N,180,321] feature tensor (this rank's shard when world > 1), as one GPU tensor."""
+    from .dataloaders import FlatBatcher
+    model.eval()
+    outs = []
+    for feats, _ in FlatBatcher(features, None, batch_size, device=device, rank=rank, world=world, dtype=input_dtype):
+        x = feats.transpose(1, 2) if swap_tf else feats          # src/predict.py:104-105
+        logits = model(x).squeeze(-1)
+        outs.append(torch.sigmoid(logits) if apply_sigmoid else logits)
+    return torch.cat(outs) if outs else torch.empty(0, device=device)
+
+
+def write_predictions(uttids, scores, out_path: str) -> pd.DataFrame:
+    """prediction.pkl exactly as src/predict.py:116-122 writes it (uttid object column, float64 predictions)."""
+    scores = [float(s) for s in scores]
+    if len(scores) != len(uttids):
+        raise ValueError("Number of predictions does not match number of rows in features.pkl")
+    df = pd.DataFrame({"uttid": uttids, "predictions": scores})
+    df.to_pickle(out_path)
+    return df
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Generate prediction.pkl from a model checkpoint (MI355X HIP path).")
+    p.add_argument("--features", required=True, help="Path to features.pkl")
+    p.add_argument("--checkpoint", required=True, help="Path to model checkpoint")
+    p.add_argument("--model", required=True, choices=["cnn2d", "cnn1d"])
+    p.add_argument("--out", required=True, help="Output path for prediction.pkl")
+    p.add_argument("--batch-size", type=int, default=32)
+    p.add_argument("--num-workers", type=int, default=2)
+    p.add_argument("--device", default=None, help="cuda (the HIP path has no CPU fallback)")
+    p.add_argument("--in-features", type=int, default=180)
+    p.add_argument("--dropout", type=float, default=0.3)
+    p.add_argument("--apply-sigmoid", action="store_true", default=True)
+    p.add_argument("--no-apply-sigmoid", action="store_true", default=False)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    sw = p.add_mutually_exclusive_group()
+    sw.add_argument("--swap-tf", dest="swap_tf", action="store_true", help="swap time and feature dims (default)")
+    sw.add_argument("--no-swap-tf", dest="swap_tf", action="store_false")
+    p.set_defaults(swap_tf=True)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    device = args.device or "cuda"
+    apply_sigmoid = False if args.no_apply_sigmoid else args.apply_sigmoid
+    model = build_model(args.model, args.in_features, args.dropout, args.precision).to(device)
+    load_weights(model, args.checkpoint, device)
+    model.eval()
+    features_df = pd.read_pickle(args.features)
+    if "uttid" not in features_df.columns:
+        raise ValueError("features.pkl must contain 'uttid'")
+    feats = torch.stack([f.float() for f in features_df["features"]]) if len(features_df) else torch.empty(0, 180, 321)
+    scores = predict_scores(model, feats, batch_size=args.batch_size, device=device, apply_sigmoid=apply_sigmoid,
+                            swap_tf=args.swap_tf)
+    write_predictions(features_df["uttid"].values, scores.cpu().tolist(), args.out)
+
+
+if __name__ == "__main__":
+    main()

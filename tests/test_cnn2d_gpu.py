@@ -128,3 +128,36 @@ def test_cnn2d_error_behaviour(golden):
         model(torch.zeros(1, 321, 180))                          # CPU input: no CPU path
     with pytest.raises(ValueError):
         model(torch.zeros(1, 321, 180, device="cuda", dtype=torch.float16))
+
+
+def test_predict_end_to_end_eer_parity(tmp_path, golden):
+    """features.pkl -> HIP predict -> prediction.pkl -> scorer, against the oracle run on the same features:
+    logits within 1e-4 and IDENTICAL EER/threshold index for both sigmoid and raw-logit scores (configs[0])."""
+    import pandas as pd
+    from dfa_amd import evaluation, predict
+    from oracle import torch_ref as R
+    sd, _ = golden("cnn2d_eval")
+    n = 96
+    g = torch.Generator().manual_seed(5)
+    labels = (torch.rand(n, generator=g) > 0.55).long()
+    # class-1 utterances carry a low-rank pattern so that scores separate only partly (EER strictly between 0 and 0.5)
+    pattern = torch.outer(torch.sin(torch.arange(180) / 7.0), torch.cos(torch.arange(321) / 23.0))
+    feats = [torch.randn(180, 321, generator=g) * 3.2 - 0.07 + 0.35 * labels[i] * pattern for i in range(n)]
+    fdf = pd.DataFrame({"uttid": [f"u{i:05d}" for i in range(n)], "features": feats})
+    ldf = pd.DataFrame({"uttid": [f"u{i:05d}" for i in range(n)], "label": labels.numpy()})
+    fp, lp, ck = str(tmp_path / "features.pkl"), str(tmp_path / "labels.pkl"), str(tmp_path / "cnn2d.pt")
+    fdf.to_pickle(fp)
+    ldf.to_pickle(lp)
+    torch.save({"model_state": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, ck)
+    ref_logits = R.cnn2d_forward(sd, torch.stack(feats).transpose(1, 2)).squeeze(-1).double()
+    for flag, ref_scores in (([], torch.sigmoid(ref_logits.float()).double()), (["--no-apply-sigmoid"], ref_logits)):
+        out = str(tmp_path / f"prediction{len(flag)}.pkl")
+        predict.main(["--features", fp, "--checkpoint", ck, "--model", "cnn2d", "--out", out, "--batch-size", "32"]
+                     + flag)
+        got = pd.read_pickle(out)
+        assert list(got["uttid"]) == list(fdf["uttid"])
+        np.testing.assert_allclose(got["predictions"].values, ref_scores.numpy(), atol=TOL_F32, rtol=0)
+        res = evaluation.score_prediction_file(out, lp)
+        want = O.calculate_eer(ref_scores.tolist(), labels.tolist())
+        assert res["eer"] == want[0], (res, want)
+        assert 0.0 < res["eer"] < 0.5

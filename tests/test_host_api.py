@@ -1,0 +1,178 @@
+"""CPU tests of the host side: drop-in module surface, scorer, fusion, datasets/loaders, prediction files,
+checkpoints, and that libdfa_hip.so loads and exports every symbol include/dfa_hip.h declares (no compute calls)."""
+import os
+import re
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import dfa_amd  # noqa: F401
+from dfa_amd import _lib, evaluation, fusion
+from dfa_amd.dataset import AudioDeepfakeDataset
+from dfa_amd.dataloaders import FlatBatcher, create_dataloaders, make_loader
+from dfa_amd.model import CNN2D
+from dfa_amd.predict import write_predictions
+from dfa_amd.training import load_checkpoint, save_checkpoint
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "dfa_hip.h")).read()
+    declared = set(re.findall(r"\b(dfa_[a-z0-9_]+)\s*\(", header))
+    declared.discard("dfa_ctx")
+    assert declared, "no prototypes found in include/dfa_hip.h"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libdfa_hip.so does not export {name}"
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared == bound, f"ctypes table and header disagree: {declared ^ bound}"
+    assert lib.dfa_version() == 100
+    assert lib.dfa_error_name(-1) == b"DFA_E_BAD_SHAPE"
+    assert lib.dfa_workspace_bytes(None, _lib.MODEL_CNN2D, 256, 321, 180, _lib.PREC_BF16) > 0
+
+
+# ------------------------------------------------------------------------------------------------ module surface
+def test_cnn2d_state_dict_matches_reference_layout(golden):
+    sd, _ = golden("cnn2d_eval")
+    m = CNN2D()
+    mine = m.state_dict()
+    assert list(mine.keys()) == list(sd.keys())              # same keys in the same order as the reference
+    for k, v in sd.items():
+        assert tuple(mine[k].shape) == tuple(v.shape), k
+    assert mine["conv.1.num_batches_tracked"].dtype == torch.int64
+    assert sum(p.numel() for p in m.parameters()) == 116_161
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    assert [n for n, _ in m.named_parameters()][:4] == ["conv.0.weight", "conv.0.bias", "conv.1.weight", "conv.1.bias"]
+
+
+def test_cnn2d_default_init_is_bit_identical_to_reference(golden):
+    """make_golden.py built the reference CNN2D under torch.manual_seed(7): same seed here -> same conv weights."""
+    _, g = golden("cnn2d_train")
+    torch.manual_seed(7)
+    m = CNN2D(in_features=180, dropout=0.0)
+    sd = m.state_dict()
+    for k in ("conv.0.weight", "conv.0.bias", "conv.5.weight", "conv.5.bias", "conv.10.weight", "conv.10.bias",
+              "classifier.bias"):
+        np.testing.assert_array_equal(sd[k].numpy(), g["init.sd." + k])
+    np.testing.assert_allclose(sd["classifier.weight"].numpy() * 40.0, g["init.sd.classifier.weight"], rtol=1e-6)
+
+
+def test_no_cpu_fallback():
+    m = CNN2D().eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 321, 180))
+    with pytest.raises(ValueError):
+        m(torch.zeros(321, 180))
+    with pytest.raises(ValueError):
+        CNN2D(num_classes=3)
+    with pytest.raises(ValueError):
+        CNN2D(precision="fp8")
+
+
+# ------------------------------------------------------------------------------------------------ scorer / fusion
+@pytest.mark.parametrize("k", ["sep", "mix", "inv", "one", "tie", "rng"])
+def test_calculate_eer_matches_reference(golden, k):
+    _, g = golden("host")
+    s, l = g[f"eer.{k}.scores"], g[f"eer.{k}.labels"]
+    assert evaluation.calculate_eer(s.tolist(), l.tolist()) == tuple(g[f"eer.{k}.result"])
+    thr = g[f"eer.{k}.result"][1]
+    assert tuple(float(v) for v in evaluation.confusion_at_threshold(s, l, thr)) == tuple(g[f"eer.{k}.confusion"])
+
+
+def test_fusion_matches_reference(golden):
+    _, g = golden("host")
+    np.testing.assert_array_equal(fusion.normalise_scores(g["fuse.sup"]), g["fuse.sup_norm"])
+    np.testing.assert_array_equal(fusion.normalise_scores(np.full(5, 0.25)), g["fuse.const_norm"])
+    table, best_eer, best_alpha = fusion.alpha_sweep(g["fuse.sup"], g["fuse.cae"], g["fuse.labels"].tolist())
+    np.testing.assert_array_equal(np.array(table), g["fuse.table"])
+    assert best_eer == g["fuse.table"][:, 1].min()
+    np.testing.assert_array_equal(fusion.ensemble_mean([g["fuse.sup"], g["fuse.cae"]]), g["fuse.ens_mean"])
+    np.testing.assert_array_equal(fusion.hybrid_scores(g["fuse.sup"], g["fuse.cae"], 1.0), g["fuse.sup_norm"])
+    np.testing.assert_array_equal(fusion.gather_sharded([1.0, 2.0]), np.array([1.0, 2.0]))
+
+
+# ------------------------------------------------------------------------------------------------ data
+def _write_pickles(tmp_path, n=10, T=321, with_uttid=True):
+    g = torch.Generator().manual_seed(0)
+    rows = [{"uttid": f"utt{i:04d}", "features": torch.randn(180, T, generator=g)} for i in range(n)]
+    feats = pd.DataFrame(rows)
+    if not with_uttid:
+        feats = feats.drop(columns=["uttid"])
+    labels = pd.DataFrame({"uttid": [f"utt{i:04d}" for i in reversed(range(n))], "label": [i % 2 for i in range(n)]})
+    fp, lp = str(tmp_path / "features.pkl"), str(tmp_path / "labels.pkl")
+    feats.to_pickle(fp)
+    labels.to_pickle(lp)
+    return fp, lp, feats, labels
+
+
+def test_dataset_and_loaders(tmp_path):
+    fp, lp, feats, labels = _write_pickles(tmp_path)
+    ds = AudioDeepfakeDataset(fp, lp)
+    assert len(ds) == 10
+    f0, l0 = ds[0]
+    assert f0.shape == (180, 321) and f0.dtype == torch.float32 and l0.dtype == torch.float32
+    want = labels.set_index("uttid").loc["utt0000", "label"]
+    assert float(l0) == float(want)                                   # merged on uttid, not on position
+    stack, lab = ds.stacked()
+    assert stack.shape == (10, 180, 321) and lab.shape == (10,)
+    loader = make_loader(fp, lp, batch_size=4, num_workers=0)
+    fb, lb = next(iter(loader))
+    assert fb.shape == (4, 180, 321) and lb.shape == (4,)
+    tr, dv, te = create_dataloaders(fp, lp, fp, lp, fp, batch_size=4, num_workers=0)
+    assert next(iter(te)).shape == (4, 180, 321)                      # test split: features only
+    batches = list(FlatBatcher(stack, lab, 4, device="cpu"))
+    assert [b[0].shape[0] for b in batches] == [4, 4, 2]
+    assert torch.equal(torch.cat([b[0] for b in batches]), stack)
+    # contiguous utterance shards for data-parallel inference
+    parts = [torch.cat([b[0] for b in FlatBatcher(stack, lab, 4, device="cpu", rank=r, world=3)]) for r in range(3)]
+    assert [p.shape[0] for p in parts] == [4, 4, 2] and torch.equal(torch.cat(parts), stack)
+    evaluation.verify_uttid_alignment(fp, lp)
+
+
+def test_dataset_errors(tmp_path):
+    fp, lp, _, _ = _write_pickles(tmp_path, with_uttid=False)
+    with pytest.raises(ValueError):
+        AudioDeepfakeDataset(fp, lp)
+    with pytest.raises(ValueError):
+        evaluation.verify_uttid_alignment(fp, lp)
+
+
+def test_prediction_file_schema_and_scoring(tmp_path):
+    fp, lp, feats, labels = _write_pickles(tmp_path)
+    out = str(tmp_path / "prediction.pkl")
+    scores = np.linspace(0.0, 1.0, 10)
+    df = write_predictions(feats["uttid"].values, scores, out)
+    back = pd.read_pickle(out)
+    assert list(back.columns) == ["uttid", "predictions"] and back["predictions"].dtype == np.float64
+    assert back.equals(df)
+    res = evaluation.score_prediction_file(out, lp)
+    merged = pd.merge(back, labels, on="uttid")
+    assert (res["eer"], res["threshold"]) == evaluation.calculate_eer(merged["predictions"].values,
+                                                                      merged["label"].values)
+    with pytest.raises(ValueError):
+        write_predictions(feats["uttid"].values, scores[:-1], out)
+    labels.iloc[:-1].to_pickle(lp)
+    with pytest.raises(ValueError):
+        evaluation.score_prediction_file(out, lp)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    m = CNN2D()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min")
+    args = types.SimpleNamespace(model="cnn2d", batch_size=32, lr=1e-3, dropout=0.2, in_features=180)
+    path = str(tmp_path / "run" / "cnn2d_best.pt")
+    save_checkpoint(m, opt, 3, args, path, scheduler=sched)
+    m2 = CNN2D()
+    blob = load_checkpoint(path, model=m2)
+    assert set(blob) == {"model_state", "optimizer_state", "epoch", "config", "scheduler_state"}
+    assert blob["epoch"] == 3 and blob["config"]["model_name"] == "cnn2d" and blob["config"]["hidden_dim"] is None
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(str(tmp_path / "missing.pt"))
