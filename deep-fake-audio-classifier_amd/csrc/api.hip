@@ -30,6 +30,23 @@ Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
   return p;
 }
 
+struct Cnn1dPlan {
+  size_t h1_off, h2_off, pooled_off, total;
+};
+
+Cnn1dPlan plan_cnn1d(int B, int T) {
+  Cnn1dPlan p;
+  size_t off = 0;
+  p.h1_off = off;
+  off = align_up(off + (size_t)B * 32 * T * sizeof(float), 256);
+  p.h2_off = off;
+  off = align_up(off + (size_t)B * 64 * T * sizeof(float), 256);
+  p.pooled_off = off;
+  off = align_up(off + (size_t)B * 128 * sizeof(float), 256);
+  p.total = off;
+  return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -67,6 +84,7 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   if (!ctx) return DFA_E_NULL_PTR;
   (void)hipSetDevice(ctx->device);
   if (ctx->cnn2d.packed) (void)hipFree(ctx->cnn2d.packed);
+  if (ctx->cnn1d.packed) (void)hipFree(ctx->cnn1d.packed);
   for (auto& t : ctx->slots) {
     for (auto e : t.start) (void)hipEventDestroy(e);
     for (auto e : t.stop) (void)hipEventDestroy(e);
@@ -165,6 +183,7 @@ size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, i
   (void)ctx;
   if (B < 1 || T < 1 || F < 1) return 0;
   if (model == DFA_MODEL_CNN2D) return plan_cnn2d(B, T, F, precision).total;
+  if (model == DFA_MODEL_CNN1D) return plan_cnn1d(B, T).total;
   return 0;
 }
 
@@ -211,6 +230,68 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ScopedSlot ts(ctx, 3);
     DFA_HIP_CHECK(ctx, launch_linear(emb, m.p[18], m.p[19], logits, B, 128 * F, s));
   }
+  return DFA_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ CNN1D */
+int dfa_cnn1d_set_params(dfa_ctx* ctx, const float* const* device_params, int n, int in_features, int base_channels) {
+  if (!ctx || !device_params) return DFA_E_NULL_PTR;
+  if (n != DFA_CNN1D_NPARAMS) return fail(ctx, DFA_E_BAD_SHAPE, "cnn1d expects %d parameter pointers, got %d", DFA_CNN1D_NPARAMS, n);
+  if (base_channels != 32) return fail(ctx, DFA_E_UNSUPPORTED, "cnn1d HIP path is built for base_channels=32 (got %d)", base_channels);
+  if (in_features < 1) return fail(ctx, DFA_E_BAD_SHAPE, "in_features must be positive (got %d)", in_features);
+  for (int i = 0; i < n; ++i)
+    if (!device_params[i]) return fail(ctx, DFA_E_NULL_PTR, "cnn1d parameter %d is null", i);
+  for (int i = 0; i < n; ++i) ctx->cnn1d.p[i] = device_params[i];
+  ctx->cnn1d.in_features = in_features;
+  ctx->cnn1d.have_params = true;
+  ctx->cnn1d.prepared = false;
+  return DFA_OK;
+}
+
+int dfa_cnn1d_prepare(dfa_ctx* ctx) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn1dState& m = ctx->cnn1d;
+  if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_set_params has not been called");
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int cin[3] = {m.in_features, 32, 64}, cout[3] = {32, 64, 128};
+  size_t off[3], boff[3], total = 0;
+  for (int l = 0; l < 3; ++l) { off[l] = total; total = align_up(total + (size_t)cout[l] * cin[l] * 3 * 4, 256); }
+  for (int l = 0; l < 3; ++l) { boff[l] = total; total = align_up(total + (size_t)cout[l] * 4, 256); }
+  if (m.packed) { DFA_HIP_CHECK(ctx, hipFree(m.packed)); m.packed = nullptr; }
+  DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, total));
+  for (int l = 0; l < 3; ++l) {
+    m.w[l] = (float*)((char*)m.packed + off[l]);
+    m.b[l] = (float*)((char*)m.packed + boff[l]);
+    const float* const* q = m.p + 6 * l;
+    DFA_HIP_CHECK(ctx, launch_fold_conv1d(q[0], q[1], q[2], q[3], q[4], q[5], m.w[l], m.b[l], cin[l], cout[l], ctx->stream));
+  }
+  m.prepared = true;
+  return DFA_OK;
+}
+
+int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                      int64_t stride_f, float* logits, void* workspace, size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn1dState& m = ctx->cnn1d;
+  if (!m.prepared) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_prepare has not been called since the last set_params");
+  if (!x || !logits || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, logits and workspace must be non-null");
+  if (x_dtype != DFA_DTYPE_F32) return fail(ctx, DFA_E_BAD_DTYPE, "cnn1d takes float32 input (got dtype %d)", x_dtype);
+  if (B < 1 || T < 1) return fail(ctx, DFA_E_BAD_SHAPE, "B and T must be >= 1 (got %d, %d)", B, T);
+  if (F != m.in_features)
+    return fail(ctx, DFA_E_BAD_SHAPE, "feature dim %d does not match in_features=%d of the first Conv1d (src/model_cnn1d.py:17)", F, m.in_features);
+  const Cnn1dPlan pl = plan_cnn1d(B, T);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  char* ws = (char*)workspace;
+  float *h1 = (float*)(ws + pl.h1_off), *h2 = (float*)(ws + pl.h2_off), *pooled = (float*)(ws + pl.pooled_off);
+  hipStream_t s = ctx->stream;
+  { ScopedSlot ts(ctx, 4);
+    DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, m.w[0], m.b[0], h1, B, F, 32, T, false, s)); }
+  { ScopedSlot ts(ctx, 5);
+    DFA_HIP_CHECK(ctx, launch_conv1d(h1, (int64_t)32 * T, T, 1, m.w[1], m.b[1], h2, B, 32, 64, T, false, s)); }
+  { ScopedSlot ts(ctx, 6);
+    DFA_HIP_CHECK(ctx, launch_conv1d(h2, (int64_t)64 * T, T, 1, m.w[2], m.b[2], pooled, B, 64, 128, T, true, s)); }
+  { ScopedSlot ts(ctx, 7);
+    DFA_HIP_CHECK(ctx, launch_linear(pooled, m.p[18], m.p[19], logits, B, 128, s)); }
   return DFA_OK;
 }
 

@@ -41,6 +41,15 @@ struct Cnn2dState {
   PackedConv c2, c3;
 };
 
+struct Cnn1dState {
+  const float* p[DFA_CNN1D_NPARAMS] = {nullptr};
+  bool have_params = false;
+  bool prepared = false;
+  int in_features = 0;
+  void* packed = nullptr;
+  float *w[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
+};
+
 }  // namespace dfa
 
 struct dfa_ctx {
@@ -48,6 +57,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   dfa::Cnn2dState cnn2d;
+  dfa::Cnn1dState cnn1d;
   bool timing = false;
   dfa::SlotTimer slots[dfa::kMaxSlots];
 };
@@ -108,6 +118,11 @@ hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int6
 // linear.hip
 hipError_t launch_linear(const float* emb, const float* w, const float* bias, float* logits, int B, int K,
                          hipStream_t s);
+// conv1d.hip
+hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                              const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
+hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
+                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s);
 // conv3x3_inst_*.hip
 hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s);

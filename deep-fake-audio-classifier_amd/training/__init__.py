@@ -6,3 +6,8 @@ from .checkpoint import build_config_dict, load_checkpoint, save_checkpoint  # n
 def cnn2d_train_forward(model, x, return_embedding=False):
     from .train_step import cnn2d_train_forward as _impl
     return _impl(model, x, return_embedding)
+
+
+def cnn1d_train_forward(model, x):
+    from .train_step import cnn1d_train_forward as _impl
+    return _impl(model, x)

@@ -88,12 +88,26 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
                       int64_t stride_t, int64_t stride_f, float* logits, float* embedding,
                       void* workspace, size_t workspace_bytes);
 
+/* ---- CNN1D (replaces CNN1D.forward, src/model_cnn1d.py:37-46) -------------------------------------- */
+/* params: 20 device pointers (fp32) in state_dict order without num_batches_tracked:
+ *   conv.0.{weight,bias}, conv.1.{weight,bias,running_mean,running_var}, conv.4.*, conv.5.*, conv.8.*, conv.9.*,
+ *   classifier.{weight,bias}.   base_channels must be 32; in_features is the Conv1d input-channel count. */
+#define DFA_CNN1D_NPARAMS 20
+int dfa_cnn1d_set_params(dfa_ctx* ctx, const float* const* device_params, int n, int in_features,
+                         int base_channels);
+int dfa_cnn1d_prepare(dfa_ctx* ctx);
+/* eval-mode forward, fp32 arithmetic.  x as in dfa_cnn2d_forward (fp32 only); logits: device float[B]. */
+int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                      int64_t stride_t, int64_t stride_f, float* logits, void* workspace,
+                      size_t workspace_bytes);
+
 /* ---- shared ------------------------------------------------------------------------------------ */
 size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision);
 /* names of the device kernels a forward launches, for profile post-processing ("" when unknown) */
 const char* dfa_dominant_kernel(int model, int precision);
 /* ---- per-kernel timing (HIP events recorded on the context's stream around every launch) -------------
- * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear.
+ * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear;
+ * CNN1D: 4, 5, 6 = conv blocks, 7 = linear.
  * Enable, run forwards, then read (read synchronises on the recorded events; call it outside timed regions).
  * At most 256 launches per slot are recorded between resets. */
 int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable);
