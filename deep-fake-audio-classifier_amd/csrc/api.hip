@@ -2,6 +2,7 @@
 // eval-mode forward of the reference's CNN2D (src/model.py:33-42) as four stream-ordered launches:
 //   conv1 (+BN+ReLU+pool)  ->  block 2 MFMA conv (+BN+ReLU+pool)  ->  block 3 MFMA conv (+BN+ReLU+mean_T)  ->  linear.
 #include "dfa_internal.h"
+#include "convt2x2_mfma.h"
 
 using namespace dfa;
 
@@ -47,6 +48,38 @@ Cnn1dPlan plan_cnn1d(int B, int T) {
   return p;
 }
 
+struct CaePlan {
+  int H[5], W[5];        // H[0]=T, W[0]=F, then after each 2x2 pool
+  int Hd[4], Wd[4];      // decoder outputs d1, d2, d3 and recon rows/cols
+  size_t e_off[4], raw_off, d_off[3], part_off, total;
+  int nblk;
+  bool ok;
+};
+
+CaePlan plan_cae(int B, int T, int F, int prec) {
+  CaePlan p;
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  p.H[0] = T; p.W[0] = F;
+  for (int l = 1; l <= 4; ++l) { p.H[l] = p.H[l - 1] / 2; p.W[l] = p.W[l - 1] / 2; }
+  p.Hd[0] = 2 * p.H[4]; p.Wd[0] = 2 * p.W[4];
+  p.Hd[1] = 2 * p.Hd[0]; p.Wd[1] = 2 * p.Wd[0] + 1;   // output_padding = (0, 1)
+  p.Hd[2] = 2 * p.Hd[1]; p.Wd[2] = 2 * p.Wd[1];
+  p.Hd[3] = 2 * p.Hd[2]; p.Wd[3] = 2 * p.Wd[2];
+  p.ok = (p.H[4] >= 1 && p.W[4] >= 1 && p.Wd[3] == F);
+  const int ch[4] = {32, 64, 128, 256};
+  size_t off = 0;
+  for (int l = 0; l < 4; ++l) { p.e_off[l] = off; off = align_up(off + (size_t)B * p.H[l + 1] * p.W[l + 1] * ch[l] * es, 256); }
+  p.raw_off = off;
+  if (prec == DFA_PREC_F32) off = align_up(off + (size_t)B * p.H[3] * p.W[3] * 256 * 4, 256);
+  const int dch[3] = {128, 64, 32};
+  for (int l = 0; l < 3; ++l) { p.d_off[l] = off; off = align_up(off + (size_t)B * p.Hd[l] * p.Wd[l] * dch[l] * es, 256); }
+  p.nblk = cae_dec4_blocks(T, p.Wd[2]);
+  p.part_off = off;
+  off = align_up(off + (size_t)B * p.nblk * sizeof(float), 256);
+  p.total = off;
+  return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -85,6 +118,7 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->cnn2d.packed) (void)hipFree(ctx->cnn2d.packed);
   if (ctx->cnn1d.packed) (void)hipFree(ctx->cnn1d.packed);
+  if (ctx->cae.packed) (void)hipFree(ctx->cae.packed);
   for (auto& t : ctx->slots) {
     for (auto e : t.start) (void)hipEventDestroy(e);
     for (auto e : t.stop) (void)hipEventDestroy(e);
@@ -173,8 +207,8 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   m.c3.wpack = (uint4*)(wp + w2_bytes);
   const float* const* p = m.p;
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, ctx->stream));
-  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream));
-  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 0, 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 0, 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
   m.prepared_prec = precision;
   return DFA_OK;
 }
@@ -184,6 +218,7 @@ size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, i
   if (B < 1 || T < 1 || F < 1) return 0;
   if (model == DFA_MODEL_CNN2D) return plan_cnn2d(B, T, F, precision).total;
   if (model == DFA_MODEL_CNN1D) return plan_cnn1d(B, T).total;
+  if (model == DFA_MODEL_CAE) return plan_cae(B, T, F, precision).total;
   return 0;
 }
 
@@ -292,6 +327,119 @@ int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     DFA_HIP_CHECK(ctx, launch_conv1d(h2, (int64_t)64 * T, T, 1, m.w[2], m.b[2], pooled, B, 64, 128, T, true, s)); }
   { ScopedSlot ts(ctx, 7);
     DFA_HIP_CHECK(ctx, launch_linear(pooled, m.p[18], m.p[19], logits, B, 128, s)); }
+  return DFA_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ CAE */
+int dfa_cae_set_params(dfa_ctx* ctx, const float* const* device_params, int n, int base_channels) {
+  if (!ctx || !device_params) return DFA_E_NULL_PTR;
+  if (n != DFA_CAE_NPARAMS) return fail(ctx, DFA_E_BAD_SHAPE, "cae expects %d parameter pointers, got %d", DFA_CAE_NPARAMS, n);
+  if (base_channels != 32) return fail(ctx, DFA_E_UNSUPPORTED, "cae HIP path is built for base_channels=32 (got %d)", base_channels);
+  for (int i = 0; i < n; ++i)
+    if (!device_params[i]) return fail(ctx, DFA_E_NULL_PTR, "cae parameter %d is null", i);
+  for (int i = 0; i < n; ++i) ctx->cae.p[i] = device_params[i];
+  ctx->cae.have_params = true;
+  ctx->cae.prepared_prec = -1;
+  return DFA_OK;
+}
+
+int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  CaeState& m = ctx->cae;
+  if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_set_params has not been called");
+  if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int ecin[3] = {32, 64, 128}, ecout[3] = {64, 128, 256};
+  const int dcin[3] = {256, 128, 64}, dcout[3] = {128, 64, 32};
+  size_t off = align_up((288 + 32) * sizeof(float), 256);
+  size_t eb[3], ew[3], db[3], dw[3];
+  for (int l = 0; l < 3; ++l) { eb[l] = off; off = align_up(off + ecout[l] * 4, 256); }
+  for (int l = 0; l < 3; ++l) { db[l] = off; off = align_up(off + dcout[l] * 4, 256); }
+  for (int l = 0; l < 3; ++l) { ew[l] = off; off = align_up(off + (size_t)ecout[l] * ecin[l] * 9 * 4, 256); }
+  for (int l = 0; l < 3; ++l) { dw[l] = off; off = align_up(off + (size_t)dcout[l] * dcin[l] * 4 * 4, 256); }
+  if (!m.packed) DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, off));
+  char* base = (char*)m.packed;
+  m.w1 = (float*)base;
+  m.b1 = m.w1 + 288;
+  for (int l = 0; l < 3; ++l) {
+    m.enc[l].bias = (float*)(base + eb[l]); m.enc[l].wpack = (uint4*)(base + ew[l]);
+    m.dec[l].bias = (float*)(base + db[l]); m.dec[l].wpack = (uint4*)(base + dw[l]);
+  }
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, s));
+  for (int l = 0; l < 2; ++l) {
+    const float* const* q = p + 6 * (l + 1);
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], ecin[l], 0, ecin[l], ecout[l], precision, m.enc[l].wpack, m.enc[l].bias, s));
+  }
+  {
+    const float* const* q = p + 18;
+    if (precision == DFA_PREC_BF16) {
+      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 0, 128, 256, precision, m.enc[2].wpack, m.enc[2].bias, s));
+    } else {  // two Cin halves, see conv3x3_inst_cae.hip
+      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 0, 64, 256, precision, m.enc[2].wpack, m.enc[2].bias, s));
+      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 64, 64, 256, precision,
+                                                  m.enc[2].wpack + (size_t)(256 / 32) * 9 * 8 * 64, m.enc[2].bias, s));
+    }
+  }
+  for (int l = 0; l < 3; ++l) {
+    const float* const* q = p + 24 + 6 * l;
+    DFA_HIP_CHECK(ctx, launch_fold_pack_convt2x2(q[0], q[1], q[2], q[3], q[4], q[5], dcin[l], dcout[l], precision, m.dec[l].wpack, m.dec[l].bias, s));
+  }
+  m.prepared_prec = precision;
+  return DFA_OK;
+}
+
+int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                    int64_t stride_f, const float* mu, const float* sigma, float* recon, float* latent, float* mse,
+                    void* workspace, size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  CaeState& m = ctx->cae;
+  if (m.prepared_prec < 0) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_prepare has not been called since the last set_params");
+  if (!x || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x and workspace must be non-null");
+  if ((mu == nullptr) != (sigma == nullptr)) return fail(ctx, DFA_E_NULL_PTR, "mu and sigma must both be given or both be NULL");
+  if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
+  if (B < 1) return fail(ctx, DFA_E_BAD_SHAPE, "batch must be >= 1 (got %d)", B);
+  if (T < 16) return fail(ctx, DFA_E_BAD_SHAPE, "T=%d is too short: four 2x2 average pools need T >= 16", T);
+  const int prec = m.prepared_prec;
+  const CaePlan pl = plan_cae(B, T, F, prec);
+  if (!pl.ok)
+    return fail(ctx, DFA_E_BAD_SHAPE, "F=%d: decoder would rebuild %d columns (needs F = 16*(F/16)+4, e.g. 180; src/model_cae.py:68-69)", F, pl.Wd[3]);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  if (((uintptr_t)workspace & 255) != 0) return fail(ctx, DFA_E_WORKSPACE, "workspace must be 256-byte aligned");
+  char* ws = (char*)workspace;
+  void* e[4] = {ws + pl.e_off[0], ws + pl.e_off[1], ws + pl.e_off[2], ws + pl.e_off[3]};
+  void* d[3] = {ws + pl.d_off[0], ws + pl.d_off[1], ws + pl.d_off[2]};
+  hipStream_t s = ctx->stream;
+  { ScopedSlot ts(ctx, 8);
+    DFA_HIP_CHECK(ctx, launch_cae_enc1(x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, m.w1, m.b1, e[0], prec, B, T, F, s)); }
+  const int ecout[3] = {64, 128, 256};
+  for (int l = 0; l < 3; ++l) {
+    ScopedSlot ts(ctx, 9 + l);
+    ConvArgs a{};
+    a.in = e[l]; a.wpack = m.enc[l].wpack; a.bias = m.enc[l].bias; a.out = e[l + 1];
+    a.B = B; a.H = pl.H[l + 1]; a.W = pl.W[l + 1]; a.COUT = ecout[l]; a.relu = 1;
+    hipError_t err = (l == 0) ? launch_cae_enc2(prec, a, s) : (l == 1) ? launch_cae_enc3(prec, a, s)
+                                                                        : launch_cae_enc4(prec, a, (float*)(ws + pl.raw_off), s);
+    DFA_HIP_CHECK(ctx, err);
+  }
+  if (latent) DFA_HIP_CHECK(ctx, launch_cae_latent_export(e[3], prec, latent, B, pl.H[4] * pl.W[4], 256, s));
+  const int dcin[3] = {256, 128, 64}, dcout[3] = {128, 64, 32};
+  for (int l = 0; l < 3; ++l) {
+    ScopedSlot ts(ctx, 12 + l);
+    ConvTArgs a{};
+    a.in = (l == 0) ? e[3] : d[l - 1];
+    a.wpack = m.dec[l].wpack; a.bias = m.dec[l].bias; a.out = d[l];
+    a.B = B; a.H = (l == 0) ? pl.H[4] : pl.Hd[l - 1]; a.W = (l == 0) ? pl.W[4] : pl.Wd[l - 1];
+    a.COUT = dcout[l]; a.opad_w = (l == 1) ? 1 : 0;
+    DFA_HIP_CHECK(ctx, launch_cae_dec(prec, dcin[l], a, s));
+    if (l == 1) DFA_HIP_CHECK(ctx, launch_cae_opad_col(d[1], m.dec[1].bias, prec, B * pl.Hd[1], pl.Wd[1], 64, s));
+  }
+  if (recon || mse) {
+    ScopedSlot ts(ctx, 15);
+    DFA_HIP_CHECK(ctx, launch_cae_dec4_mse(d[2], prec, m.p[42], m.p[43], x, x_dtype, stride_b, stride_t, stride_f, mu, sigma,
+                                           recon, (float*)(ws + pl.part_off), mse, B, pl.Hd[2], pl.Wd[2], T, F, s));
+  }
   return DFA_OK;
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ float cvt_out<float>(float f) { return f; }
 template <>
 __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float f) { return float_to_bf16(f); }
 
-enum { EPI_POOL_H2 = 0, EPI_POOL_2X2 = 1, EPI_MEAN_T = 2, EPI_PLAIN = 3 };
+enum { EPI_POOL_H2 = 0, EPI_POOL_2X2 = 1, EPI_MEAN_T = 2, EPI_PLAIN = 3, EPI_RAW = 4 };
 
 struct ConvArgs {
   const void* in;      // [B][H][W][CIN] T
@@ -69,6 +69,12 @@ struct ConvArgs {
   int nstrips;
   float inv_h;
   int relu;            // PLAIN only: apply ReLU (1) or not (0)
+  // K-split support (Cin larger than one launch can keep in registers, e.g. fp32 Cin = 128): a launch may read a
+  // CIN-channel window of wider pixels, start from previously stored partial sums and/or store raw partial sums.
+  int in_pix_bytes;    // bytes between consecutive input pixels (0 = CIN*sizeof(T), i.e. dense)
+  int in_ch_off_bytes; // byte offset of this launch's first input channel inside a pixel
+  const float* acc_in; // ACCIN: [B][H][W][COUT] fp32 partial sums to start from
+  float* raw_out;      // EPI_RAW: [B][H][W][COUT] fp32 partial sums (no bias, no activation)
 };
 
 template <int PB>
@@ -122,7 +128,7 @@ struct ConvCfg {
   static_assert(CIN % KG == 0, "CIN must be a multiple of the k-group");
 };
 
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW>
+template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false>
 __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<T, CIN, NSL, MG, RP, MT, EPI>;
   constexpr int PB = C::PB, CPP = C::CPP, SLOTS = C::SLOTS, BR = C::BR, NT = C::NT, NKG = C::NKG;
@@ -147,7 +153,8 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
   const int cout_base = blockIdx.y * (NSL * 32);
   const int n = cout_base + nsl * 32 + r;  // this lane's output channel
 
-  const char* in_b = (const char*)a.in + (size_t)b * H * W * PB;
+  const int ipb = a.in_pix_bytes ? a.in_pix_bytes : PB;
+  const char* in_b = (const char*)a.in + (size_t)b * H * W * ipb + a.in_ch_off_bytes;
 
   // ---- weights: the wave's [9][NKG] 16-byte B fragments stay in registers for the whole kernel
   uint4 w[9][NKG];
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         const int rem = g - rowi * (SLOTS * CPP);
         const int slot = rem / CPP, c = rem % CPP;
         const int t = BR * j - 1 + rowi, f = f0 - 1 + slot;
-        if (t >= 0 && t < H && f >= 0 && f < W) v = *(const uint4*)(in_b + ((size_t)t * W + f) * PB + c * 16);
+        if (t >= 0 && t < H && f >= 0 && f < W) v = *(const uint4*)(in_b + ((size_t)t * W + f) * ipb + c * 16);
       }
       stg[k] = v;
     }
@@ -220,6 +227,17 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       f32x16_t acc0, acc1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+      if (ACCIN) {
+        const int t0i = BR * it + 2 * rp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int f = f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (f < W) {
+            if (t0i < H) acc0[i] = a.acc_in[(((size_t)b * H + t0i) * W + f) * COUT + n];
+            if (t0i + 1 < H) acc1[i] = a.acc_in[(((size_t)b * H + t0i + 1) * W + f) * COUT + n];
+          }
+        }
+      }
 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {  // input row key q = BR*it + 2*rp + i  (input row t = q - 1)
@@ -273,6 +291,15 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
             for (int i = 0; i < 16; ++i)
               cs[mm][i] += k0 * fmaxf(acc0[i] + bv, 0.f) + k1 * fmaxf(acc1[i] + bv, 0.f);
           }
+      } else if (EPI == EPI_RAW) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int f = f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (f < W) {
+            if (t0 < H) a.raw_out[(((size_t)b * H + t0) * W + f) * COUT + n] = acc0[i];
+            if (t0 + 1 < H) a.raw_out[(((size_t)b * H + t0 + 1) * W + f) * COUT + n] = acc1[i];
+          }
+        }
       } else {  // EPI_PLAIN
         T* out = (T*)a.out;
 #pragma unroll
@@ -312,12 +339,12 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
 }
 
 // host-side launcher (defined per instantiation in conv3x3_inst_*.hip)
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW>
+template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false>
 hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<T, CIN, NSL, MG, RP, MT, EPI>;
   ConvArgs a = a0;
   a.nstrips = (a.W + 32 * MT - 1) / (32 * MT);
-  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW>;
+  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

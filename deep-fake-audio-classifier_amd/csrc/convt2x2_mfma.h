@@ -1,0 +1,111 @@
+// convt2x2_mfma.h -- ConvTranspose2d(kernel 2, stride 2) + BatchNorm(eval, folded) + ReLU on the matrix cores
+// (src/model_cae.py:63-65, 68-71, 74-76).
+//
+// kernel == stride  =>  the transposed convolution does not overlap: every input pixel (i,j) produces its own 2x2
+// output patch,   out[2i+a][2j+c][co] = bias[co] + sum_ci x[i][j][ci] * W[ci][co][a][c]
+// i.e. one GEMM  [pixels x Cin] . [Cin x 4*Cout]  followed by a pixel shuffle (exact).
+// GEMM column n = (2a+c)*Cout + co.  Input/output activations are channels-last, so the input tile of a workgroup
+// (MSUB*32 consecutive pixels of the flattened [B*H*W] index) is ONE contiguous block of HBM -> LDS, no halo.
+// A fragments come from LDS with the same chunk swizzle as conv3x3_mfma; each wave walks the 32-column N slices
+// assigned to it, loading that slice's B fragments (Cin/KG x 16 bytes per lane) once per workgroup tile.
+#pragma once
+#include "conv3x3_mfma.h"
+
+namespace dfa {
+
+struct ConvTArgs {
+  const void* in;      // [B][H][W][CIN] T
+  const uint4* wpack;  // [4*COUT/32][CIN/KG][64] x 16 bytes
+  const float* bias;   // [COUT] folded
+  void* out;           // [B][2H][2W+opad_w][COUT] T
+  int B, H, W, COUT, opad_w;
+};
+
+template <typename T, int CIN, int MSUB>
+__global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
+  constexpr int ES = sizeof(T), KG = 32 / ES, NKG = CIN / KG, PB = CIN * ES, CPP = PB / 16;
+  constexpr int MTILE = 32 * MSUB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* obase = (int*)(smem + MTILE * PB);  // per tile pixel: output pixel index of (2i, 2j), or -1
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, COUT = a.COUT;
+  const int Ho = 2 * H, Wo = 2 * W + a.opad_w;
+  const long P = (long)a.B * H * W;
+  const long g0 = (long)blockIdx.x * MTILE;
+
+  // stage the contiguous input tile (zero beyond the last pixel)
+  const char* src = (const char*)a.in + g0 * PB;
+  for (int g = tid; g < MTILE * CPP; g += 256) {
+    const int p = g / CPP, c = g % CPP;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (g0 + p < P) v = *(const uint4*)(src + (size_t)g * 16);
+    *(uint4*)(smem + p * PB + ((c ^ lds_swz<(PB > 512 ? 512 : PB)>(p)) << 4)) = v;
+  }
+  for (int p = tid; p < MTILE; p += 256) {
+    const long g = g0 + p;
+    int v = -1;
+    if (g < P) {
+      const int bb = (int)(g / ((long)H * W));
+      const int rem = (int)(g - (long)bb * H * W);
+      const int ii = rem / W, jj = rem - ii * W;
+      v = (bb * Ho + 2 * ii) * Wo + 2 * jj;
+    }
+    obase[p] = v;
+  }
+  __syncthreads();
+
+  const int nslices = 4 * COUT / 32;
+  T* out = (T*)a.out;
+  for (int s = wave; s < nslices; s += 4) {
+    uint4 wb[NKG];
+    const uint4* wp = a.wpack + (size_t)s * NKG * 64 + lane;
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) wb[kg] = wp[kg * 64];
+    const int nglob = s * 32;            // all 32 columns of a slice share the patch position q (COUT % 32 == 0)
+    const int q = nglob / COUT;
+    const int co = nglob - q * COUT + r;
+    const int oshift = (q >> 1) * Wo + (q & 1);
+    const float bv = a.bias[co];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+      f32x16_t acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const int p = ms * 32 + r;
+      const int sw = lds_swz<(PB > 512 ? 512 : PB)>(p);
+      const char* base = smem + p * PB;
+#pragma unroll
+      for (int kg = 0; kg < NKG; ++kg) {
+        const uint4 av = *(const uint4*)(base + (((2 * kg + h) ^ sw) << 4));
+        acc = Mma<T>::run(av, wb[kg], acc);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ob = obase[ms * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+        if (ob >= 0) out[(size_t)(ob + oshift) * COUT + co] = cvt_out<T>(fmaxf(acc[i] + bv, 0.f));
+      }
+    }
+  }
+}
+
+template <typename T, int CIN, int MSUB>
+hipError_t launch_convt2x2(const ConvTArgs& a, hipStream_t stream) {
+  constexpr int PB = CIN * (int)sizeof(T), MTILE = 32 * MSUB;
+  constexpr int LDS = MTILE * PB + MTILE * 4;
+  auto kern = convt2x2_mfma_kernel<T, CIN, MSUB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long P = (long)a.B * a.H * a.W;
+  dim3 grid((unsigned)((P + MTILE - 1) / MTILE)), block(256);
+  hipLaunchKernelGGL(kern, grid, block, LDS, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

@@ -50,6 +50,16 @@ struct Cnn1dState {
   float *w[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
 };
 
+struct CaeState {
+  const float* p[DFA_CAE_NPARAMS] = {nullptr};
+  bool have_params = false;
+  int prepared_prec = -1;
+  void* packed = nullptr;
+  float *w1 = nullptr, *b1 = nullptr;
+  PackedConv enc[3];   // encoder blocks 2-4
+  PackedConv dec[3];   // decoder blocks 1-3 (ConvTranspose2d images)
+};
+
 }  // namespace dfa
 
 struct dfa_ctx {
@@ -58,6 +68,7 @@ struct dfa_ctx {
   char err[512] = {0};
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
+  dfa::CaeState cae;
   bool timing = false;
   dfa::SlotTimer slots[dfa::kMaxSlots];
 };
@@ -110,8 +121,11 @@ struct ScopedSlot {
 hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                              const float* var, float* w1, float* b1, int cout, hipStream_t s);
 hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
-                                    const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
-                                    float* bias, hipStream_t s);
+                                    const float* mean, const float* var, int cin_total, int cin_off, int cin, int cout,
+                                    int prec, uint4* wpack, float* bias, hipStream_t s);
+hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float* g, const float* beta,
+                                     const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
+                                     float* bias, hipStream_t s);
 // conv1.hip
 hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
                         const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s);
@@ -123,8 +137,23 @@ hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, co
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
                          float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s);
+// cae.hip
+hipError_t launch_cae_enc1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu,
+                           const float* sigma, const float* w1, const float* b1, void* out, int prec, int B, int T, int F,
+                           hipStream_t s);
+hipError_t launch_cae_opad_col(void* out, const float* bias, int prec, int rows, int Wo, int C, hipStream_t s);
+int cae_dec4_blocks(int T, int W3);
+hipError_t launch_cae_dec4_mse(const void* d3, int prec, const float* w4, const float* b4, const void* x, int x_dtype,
+                               int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon,
+                               float* partial, float* mse, int B, int H3, int W3, int T, int F, hipStream_t s);
+hipError_t launch_cae_latent_export(const void* lat, int prec, float* out, int B, int HW, int C, hipStream_t s);
 // conv3x3_inst_*.hip
 hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s);
+struct ConvTArgs;
+hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_cae_dec(int prec, int cin, const ConvTArgs& a, hipStream_t s);
 
 }  // namespace dfa

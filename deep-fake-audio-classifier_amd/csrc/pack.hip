@@ -30,8 +30,9 @@ __global__ void fold_conv1_kernel(const float* __restrict__ w, const float* __re
 template <typename T>
 __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                          const float* __restrict__ g, const float* __restrict__ beta,
-                                         const float* __restrict__ mean, const float* __restrict__ var, int cin,
-                                         int cout, uint4* __restrict__ wpack, float* __restrict__ bias) {
+                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                         int cin_total, int cin_off, int cin, int cout, uint4* __restrict__ wpack,
+                                         float* __restrict__ bias) {
   constexpr int KG = 32 / (int)sizeof(T);
   constexpr int EPL = KG / 2;  // elements per lane per k-group
   const int nkg = cin / KG;
@@ -54,7 +55,7 @@ __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const floa
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
     const int ci = KG * kg + EPL * hh + j;
-    v[j] = cvt_out<T>(w[((size_t)co * cin + ci) * 9 + tap] * s);
+    v[j] = cvt_out<T>(w[((size_t)co * cin_total + cin_off + ci) * 9 + tap] * s);
   }
   wpack[i] = *reinterpret_cast<const uint4*>(v);
 }
@@ -68,17 +69,63 @@ hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, con
 }
 
 hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
-                                    const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
-                                    float* bias, hipStream_t s) {
+                                    const float* mean, const float* var, int cin_total, int cin_off, int cin, int cout,
+                                    int prec, uint4* wpack, float* bias, hipStream_t s) {
   const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
   int total = (cout / 32) * 9 * (cin / kg) * 64;
   if (total < cout) total = cout;
   dim3 grid((total + 255) / 256), block(256);
   if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(fold_pack_conv3x3_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
+    hipLaunchKernelGGL(fold_pack_conv3x3_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin_total, cin_off,
+                       cin, cout, wpack, bias);
+  else
+    hipLaunchKernelGGL(fold_pack_conv3x3_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin_total, cin_off, cin,
+                       cout, wpack, bias);
+  return hipGetLastError();
+}
+
+// ConvTranspose2d k2 s2 (+ BN fold): w[CIN][COUT][2][2] -> wpack[4*COUT/32][CIN/KG][64][16 B]; GEMM column
+// n = (2a+c)*COUT + co; lane (r,h) element j = s[co] * w[ci = KG*kg + (KG/2)*h + j][co][a][c].
+template <typename T>
+__global__ void fold_pack_convt2x2_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                          const float* __restrict__ g, const float* __restrict__ beta,
+                                          const float* __restrict__ mean, const float* __restrict__ var, int cin,
+                                          int cout, uint4* __restrict__ wpack, float* __restrict__ bias) {
+  constexpr int KG = 32 / (int)sizeof(T);
+  constexpr int EPL = KG / 2;
+  const int nkg = cin / KG;
+  const int total = (4 * cout / 32) * nkg * 64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout) bias[i] = (b[i] - mean[i]) * (g[i] / sqrtf(var[i] + kBnEps)) + beta[i];
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int kg = rest % nkg;
+  const int slice = rest / nkg;
+  const int n = slice * 32 + (lane & 31), hh = lane >> 5;
+  const int q = n / cout, co = n - q * cout;
+  const float s = g[co] / sqrtf(var[co] + kBnEps);
+  T v[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int ci = KG * kg + EPL * hh + j;
+    v[j] = cvt_out<T>(w[((size_t)ci * cout + co) * 4 + q] * s);
+  }
+  wpack[i] = *reinterpret_cast<const uint4*>(v);
+}
+
+hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float* g, const float* beta,
+                                     const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
+                                     float* bias, hipStream_t s) {
+  const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
+  int total = (4 * cout / 32) * (cin / kg) * 64;
+  if (total < cout) total = cout;
+  dim3 grid((total + 255) / 256), block(256);
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL(fold_pack_convt2x2_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
                        bias);
   else
-    hipLaunchKernelGGL(fold_pack_conv3x3_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
+    hipLaunchKernelGGL(fold_pack_convt2x2_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
                        bias);
   return hipGetLastError();
 }

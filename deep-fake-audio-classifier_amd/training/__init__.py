@@ -11,3 +11,8 @@ def cnn2d_train_forward(model, x, return_embedding=False):
 def cnn1d_train_forward(model, x):
     from .train_step import cnn1d_train_forward as _impl
     return _impl(model, x)
+
+
+def cae_train_forward(model, x):
+    from .train_step import cae_train_forward as _impl
+    return _impl(model, x)

@@ -101,13 +101,33 @@ int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
                       int64_t stride_t, int64_t stride_f, float* logits, void* workspace,
                       size_t workspace_bytes);
 
+/* ---- ConvAutoencoder (replaces ConvAutoencoder.forward, src/model_cae.py:83-125, and the per-sample MSE of
+ *      src/evaluation_cae.py:52-53 / src/hybrid_ensemble.py:55) ------------------------------------------------ */
+/* params: 44 device pointers (fp32) in state_dict order without num_batches_tracked:
+ *   encoder.{0,4,8,12}.{weight,bias} each followed by encoder.{1,5,9,13}.{weight,bias,running_mean,running_var};
+ *   decoder.{0,3,6}.{weight,bias} each followed by decoder.{1,4,7}.{weight,bias,running_mean,running_var};
+ *   decoder.9.{weight,bias}.   ConvTranspose2d weights keep torch's (Cin, Cout, 2, 2) layout.  base_channels = 32. */
+#define DFA_CAE_NPARAMS 44
+int dfa_cae_set_params(dfa_ctx* ctx, const float* const* device_params, int n, int base_channels);
+int dfa_cae_prepare(dfa_ctx* ctx, int precision);
+/* eval-mode forward.  x as in dfa_cnn2d_forward; T >= 16; F must satisfy F == 16*(F/16) + 4 (180 does), because
+ * the decoder's output_padding=(0,1) is fixed (src/model_cae.py:68-69).
+ *   mu, sigma: device float[F] or both NULL.  When given, the FeatureNormalizer z-score (x - mu[f]) / sigma[f]
+ *              (src/dataset_cae.py:37-41) is fused into every read of x, i.e. x is the RAW feature tensor;
+ *   recon:  device float[B*T*F] or NULL  -- reconstruction, rows >= 16*(T/16) are zero (model_cae.py:116-119);
+ *   latent: device float[B*256*(T/16)*(F/16)] (NCHW) or NULL;
+ *   mse:    device float[B] or NULL      -- mean over T*F of (recon - x_normalised)^2. */
+int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                    int64_t stride_t, int64_t stride_f, const float* mu, const float* sigma, float* recon,
+                    float* latent, float* mse, void* workspace, size_t workspace_bytes);
+
 /* ---- shared ------------------------------------------------------------------------------------ */
 size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision);
 /* names of the device kernels a forward launches, for profile post-processing ("" when unknown) */
 const char* dfa_dominant_kernel(int model, int precision);
 /* ---- per-kernel timing (HIP events recorded on the context's stream around every launch) -------------
  * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear;
- * CNN1D: 4, 5, 6 = conv blocks, 7 = linear.
+ * CNN1D: 4, 5, 6 = conv blocks, 7 = linear;  CAE: 8 = enc1, 9-11 = enc2-4 (MFMA), 12-14 = dec1-3 (MFMA), 15 = dec4+MSE.
  * Enable, run forwards, then read (read synchronises on the recorded events; call it outside timed regions).
  * At most 256 launches per slot are recorded between resets. */
 int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable);

@@ -1,0 +1,77 @@
+"""GPU parity tests for the ConvAutoencoder path (HIP kernels through the C ABI vs golden vectors / oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dfa_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(sd, precision="fp32"):
+    from dfa_amd.model_cae import ConvAutoencoder
+    m = ConvAutoencoder(precision=precision)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return m.to("cuda").eval()
+
+
+@pytest.mark.parametrize("tag", ["t321", "t64", "t70"])
+def test_cae_fp32_matches_golden(golden, tag):
+    sd, g = golden("cae_eval")
+    model = _model(sd)
+    x = torch.from_numpy(g[f"{tag}.x"]).to("cuda")
+    recon, latent = model(x)
+    assert recon.shape == x.shape and tuple(latent.shape) == g[f"{tag}.latent"].shape
+    np.testing.assert_allclose(latent.cpu().numpy(), g[f"{tag}.latent"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(recon.cpu().numpy(), g[f"{tag}.recon"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(model.score(x).cpu().numpy(), g[f"{tag}.mse"], rtol=1e-5)
+    T = x.shape[1]
+    if T % 16:
+        assert torch.all(recon[:, 16 * (T // 16):, :] == 0)      # zero-padded tail (model_cae.py:116-119)
+
+
+def test_cae_fused_zscore_and_strided_input(golden):
+    sd, g = golden("cae_eval")
+    model = _model(sd)
+    stored = torch.from_numpy(g["raw.x_stored"]).to("cuda")       # raw [B,180,321]
+    mean, std = torch.from_numpy(g["raw.mean"]), torch.from_numpy(g["raw.std"])
+    mse = model.score(stored.transpose(1, 2), mean, std)           # strided view + fused (x-mean)/std
+    np.testing.assert_allclose(mse.cpu().numpy(), g["raw.mse"], rtol=1e-5)
+    xz = (stored.transpose(1, 2) - mean.to("cuda")) / std.to("cuda")
+    recon, _ = model(xz)
+    np.testing.assert_allclose(recon.cpu().numpy(), g["raw.recon"], atol=2e-5, rtol=1e-5)
+
+
+def test_cae_bf16_mode_close(golden):
+    sd, g = golden("cae_eval")
+    model = _model(sd, precision="bf16")
+    x = torch.from_numpy(g["t321.x"]).to("cuda")
+    recon, latent = model(x)
+    # bf16 storage / fp32 accumulate through 8 layers: loose tolerance, this is the throughput mode
+    assert np.abs(recon.cpu().numpy() - g["t321.recon"]).max() < 0.08
+    np.testing.assert_allclose(model.score(x).cpu().numpy(), g["t321.mse"], rtol=2e-2)
+
+
+def test_cae_full_batch_independence_and_oracle(golden):
+    sd, _ = golden("cae_eval")
+    model = _model(sd)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(64, 321, 180, generator=g) * 1.2).to("cuda")
+    mse = model.score(x).cpu().numpy()
+    one = model.score(x[37:38]).cpu().numpy()
+    np.testing.assert_allclose(one, mse[37:38], rtol=1e-6)
+    recon, _ = O.cae_forward(sd, x[:2].cpu().numpy())
+    np.testing.assert_allclose(mse[:2], O.per_sample_mse(recon, x[:2].cpu().numpy()), rtol=1e-5)
+
+
+def test_cae_errors(golden):
+    sd, _ = golden("cae_eval")
+    model = _model(sd)
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 321, 176, device="cuda"))       # F must be 16k+4 for the fixed output_padding
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 8, 180, device="cuda"))         # T < 16
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 321, 180))
+    with pytest.raises(ValueError):
+        model.score(torch.zeros(1, 321, 180, device="cuda"), mean=torch.zeros(180))
