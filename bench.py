@@ -32,6 +32,20 @@ BLOCK3_FLOPS_PER_UTT = 2 * 1_061_683_200  # Conv2d 64->128 on (80,180): the domi
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
 
 
+def pmc_traffic(prec):
+    """HBM bytes per launch of the block-3 kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json;
+    counters cannot be read from inside this process).  None if the summary is absent."""
+    try:
+        blob = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    tag = "dfa::bf16_t, 64, 4" if prec == "bf16" else "float, 64, 4"
+    for name, rec in blob.get("kernels", {}).items():
+        if "conv3x3_mfma_kernel<" + tag in name:
+            return rec.get("hbm_bytes_per_launch")
+    return None
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -157,7 +171,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (CNN2D block 3, 64->128, +BN+ReLU+mean_T)",
                          "achieved": round(ach, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_TFLOPS[prec], 4), "traffic": None,
+                         "frac": round(ach / PEAK_TFLOPS[prec], 4),
+                         "traffic": pmc_traffic(prec) if B == B_PER_GPU else None,
                          "kernel_ms": round(k_ms, 4), "launches_timed": n3},
             "kernel_ms": {name: round(ms / max(n, 1), 4) for name, (ms, n) in
                           zip(("conv1", "block2_mfma", "block3_mfma", "linear"), slots)},
