@@ -28,12 +28,23 @@ SYMBOLS = [
     ("dfa_ctx_create", C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("dfa_ctx_destroy", C.c_int, [C.c_void_p]),
     ("dfa_ctx_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dfa_ctx_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("dfa_last_error", C.c_char_p, [C.c_void_p]),
     ("dfa_error_name", C.c_char_p, [C.c_int]),
     ("dfa_cnn2d_set_params", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     ("dfa_cnn2d_prepare", C.c_int, [C.c_void_p, C.c_int]),
     ("dfa_cnn2d_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("dfa_cnn2d_train_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("dfa_cnn2d_forward_train", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                          C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_float,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("dfa_cnn2d_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                     C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
+    ("dfa_bce_smooth_fwd_bwd", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
+    ("dfa_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]),
     ("dfa_cnn1d_set_params", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     ("dfa_cnn1d_prepare", C.c_int, [C.c_void_p]),
     ("dfa_cnn1d_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
@@ -114,6 +125,9 @@ class Context:
             self._ws = None
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", self.index))
         return self._ws
+
+    def set_option(self, name: str, value: int):
+        check(self.handle, self.lib.dfa_ctx_set_option(self.handle, name.encode(), int(value)))
 
     # ---- timing -----------------------------------------------------------------------------------------------
     def timing(self, enable: bool):

@@ -1,6 +1,8 @@
 // api.hip -- the C ABI of libdfa_hip.so (include/dfa_hip.h): context lifecycle, weight preparation and the
 // eval-mode forward of the reference's CNN2D (src/model.py:33-42) as four stream-ordered launches:
 //   conv1 (+BN+ReLU+pool)  ->  block 2 MFMA conv (+BN+ReLU+pool)  ->  block 3 MFMA conv (+BN+ReLU+mean_T)  ->  linear.
+#include <stdlib.h>
+
 #include "dfa_internal.h"
 #include "convt2x2_mfma.h"
 
@@ -109,6 +111,12 @@ int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out) {
   dfa_ctx* c = new dfa_ctx();
   c->device = device_id;
   c->stream = (hipStream_t)hip_stream;
+  if (hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
+    delete c;
+    return DFA_E_HIP;
+  }
+  const char* dma = getenv("DFA_CONV_DMA");
+  c->conv_dma = (dma && dma[0] == '1') ? 1 : 0;
   *out = c;
   return DFA_OK;
 }
@@ -117,8 +125,10 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   if (!ctx) return DFA_E_NULL_PTR;
   (void)hipSetDevice(ctx->device);
   if (ctx->cnn2d.packed) (void)hipFree(ctx->cnn2d.packed);
+  if (ctx->cnn2d.train_packed) (void)hipFree(ctx->cnn2d.train_packed);
   if (ctx->cnn1d.packed) (void)hipFree(ctx->cnn1d.packed);
   if (ctx->cae.packed) (void)hipFree(ctx->cae.packed);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   for (auto& t : ctx->slots) {
     for (auto e : t.start) (void)hipEventDestroy(e);
     for (auto e : t.stop) (void)hipEventDestroy(e);
@@ -134,6 +144,12 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream) {
 }
 
 const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return DFA_E_NULL_PTR;
+  if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value ? 1 : 0; return DFA_OK; }
+  return fail(ctx, DFA_E_UNSUPPORTED, "unknown option '%s'", name);
+}
 
 int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable) {
   if (!ctx) return DFA_E_NULL_PTR;
@@ -251,15 +267,15 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ScopedSlot ts(ctx, 1);
     ConvArgs a{};
     a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;
-    a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1;
-    DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s));
+    a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma));
   }
   {
     ScopedSlot ts(ctx, 2);
     ConvArgs a{};
     a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
-    a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1;
-    DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s));
+    a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma));
   }
   {
     ScopedSlot ts(ctx, 3);

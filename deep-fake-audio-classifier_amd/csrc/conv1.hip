@@ -6,6 +6,7 @@
 // tensor (src/predict.py:105) is read along its contiguous axis, and every lane writes its pixel's 32 output
 // channels as 16-byte stores into the channels-last activation the MFMA blocks consume.
 #include "dfa_internal.h"
+#include "rng.h"
 
 namespace dfa {
 
@@ -25,7 +26,7 @@ template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __restrict__ x, int64_t sb, int64_t st,
                                                                    int64_t sf, const float* __restrict__ w1,
                                                                    const float* __restrict__ b1, TO* __restrict__ out,
-                                                                   int T, int F, int Ho) {
+                                                                   int T, int F, int Ho, DropCfg dc) {
   __shared__ float xs[C1_XR][C1_XC + 1];
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
 
   TO* op = out + (((size_t)b * Ho + i) * F + f) * 32;
   constexpr int VEC = 16 / (int)sizeof(TO);  // output channels per 16-byte store
+  float ds[32];                                // train mode: dropout keep-scale of this pixel's 32 channels
+  if (dc.thresh != 0) {
+#pragma unroll
+    for (int c0 = 0; c0 < 32; c0 += 8) drop_scale8(dc, (((uint64_t)b * Ho + i) * F + f) * 32 + c0, ds + c0);
+  }
 #pragma unroll
   for (int c0 = 0; c0 < 32; c0 += VEC) {
     TO ov[VEC];
@@ -68,28 +74,33 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
           v0 = fmaf(wc[dy * 3 + d], xv[dy][d], v0);
           v1 = fmaf(wc[dy * 3 + d], xv[dy + 1][d], v1);
         }
-      ov[c] = cvt_out<TO>(0.5f * (fmaxf(v0, 0.f) + fmaxf(v1, 0.f)));
+      float o = 0.5f * (fmaxf(v0, 0.f) + fmaxf(v1, 0.f));
+      if (dc.thresh != 0) o *= ds[c0 + c];
+      ov[c] = cvt_out<TO>(o);
     }
     *reinterpret_cast<uint4*>(op + c0) = *reinterpret_cast<const uint4*>(ov);
   }
 }
 
 hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
-                        const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s) {
+                        const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s,
+                        const DropCfg* drop) {
+  DropCfg dc{};
+  if (drop) dc = *drop;
   const int Ho = T / 2;
   dim3 grid((F + C1_TF - 1) / C1_TF, (Ho + C1_TI - 1) / C1_TI, B), block(256);
   if (x_dtype == DFA_DTYPE_F32 && out_prec == DFA_PREC_F32)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, float>), grid, block, 0, s, (const float*)x, sb, st, sf, w1,
-                       b1, (float*)out, T, F, Ho);
+                       b1, (float*)out, T, F, Ho, dc);
   else if (x_dtype == DFA_DTYPE_F32 && out_prec == DFA_PREC_BF16)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, sb, st, sf,
-                       w1, b1, (bf16_t*)out, T, F, Ho);
+                       w1, b1, (bf16_t*)out, T, F, Ho, dc);
   else if (x_dtype == DFA_DTYPE_BF16 && out_prec == DFA_PREC_F32)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, sb, st, sf,
-                       w1, b1, (float*)out, T, F, Ho);
+                       w1, b1, (float*)out, T, F, Ho, dc);
   else
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, sb, st, sf,
-                       w1, b1, (bf16_t*)out, T, F, Ho);
+                       w1, b1, (bf16_t*)out, T, F, Ho, dc);
   return hipGetLastError();
 }
 

@@ -6,12 +6,21 @@
 
 namespace dfa {
 
-hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s) {
+// dma = 1: stage the input ring with global_load_lds (LDS-DMA) instead of through registers.
+hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma) {
+  if (dma) {
+    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_H2, 2, false, true>(a, s);
+    return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_POOL_H2, 1, false, true>(a, s);
+  }
   if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_H2, 2>(a, s);
   return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_POOL_H2, 1>(a, s);
 }
 
-hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s) {
+hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma) {
+  if (dma) {
+    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_MEAN_T, 2, false, true>(a, s);
+    return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_MEAN_T, 1, false, true>(a, s);
+  }
   if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_MEAN_T, 2>(a, s);
   return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_MEAN_T, 1>(a, s);
 }

@@ -75,6 +75,10 @@ struct ConvArgs {
   int in_ch_off_bytes; // byte offset of this launch's first input channel inside a pixel
   const float* acc_in; // ACCIN: [B][H][W][COUT] fp32 partial sums to start from
   float* raw_out;      // EPI_RAW: [B][H][W][COUT] fp32 partial sums (no bias, no activation)
+  // train-mode BatchNorm statistics (EPI_PLAIN only): per-workgroup partial sums of the stored values v and v*v
+  // per output channel, partial[(blockIdx.x * COUT + channel) * 2 + {0,1}]; reduced in a fixed order by bn_finalize.
+  float* stats_partial;
+  const void* zero_page;  // DMA staging: >= 16 zero bytes in device memory (source of out-of-image chunks)
 };
 
 template <int PB>
@@ -128,7 +132,7 @@ struct ConvCfg {
   static_assert(CIN % KG == 0, "CIN must be a multiple of the k-group");
 };
 
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false>
+template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false>
 __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<T, CIN, NSL, MG, RP, MT, EPI>;
   constexpr int PB = C::PB, CPP = C::CPP, SLOTS = C::SLOTS, BR = C::BR, NT = C::NT, NKG = C::NKG;
@@ -198,6 +202,30 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
     }
   };
 
+  // LDS-DMA variant (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  One wave instruction fills 64
+  // consecutive PHYSICAL 16-byte chunks (1 KiB, wave-uniform LDS base + lane*16), so the chunk swizzle is applied to
+  // the per-lane SOURCE address: the lane that owns physical chunk c' of pixel p fetches logical chunk c' ^ swz(p).
+  // Out-of-image chunks read a 16-byte zero page.  The transfers are retired by the vmcnt(0) hipcc emits at the
+  // iteration's __syncthreads().
+  auto stage_dma = [&](int j, int ringblk) {
+#pragma unroll
+    for (int k = 0; k < C::NLD; ++k) {
+      const int g = k * NT + tid;
+      if (g < C::NCH) {
+        const int pix = g / CPP, cph = g % CPP;
+        const int rowi = pix / SLOTS, slot = pix - rowi * SLOTS;
+        const int p = ringblk * BR * SLOTS + pix;
+        const int c = cph ^ lds_swz<PB>(p);
+        const int t = BR * j - 1 + rowi, f = f0 - 1 + slot;
+        const char* src = (t >= 0 && t < H && f >= 0 && f < W) ? in_b + ((size_t)t * W + f) * ipb + c * 16
+                                                               : (const char*)a.zero_page;
+        char* dst = smem + ((size_t)ringblk * BR * SLOTS * CPP + k * NT + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
   float cs[EPI == EPI_MEAN_T ? MT : 1][16];
   if (EPI == EPI_MEAN_T) {
 #pragma unroll
@@ -206,11 +234,17 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       for (int i = 0; i < 16; ++i) cs[m][i] = 0.f;
   }
 
+  float st1 = 0.f, st2 = 0.f;  // EPI_PLAIN: running sum / sum of squares of this lane's channel
   const int niter = (H + BR - 1) / BR;
-  stage_load(0);
-  stage_store(0);
-  stage_load(1);
-  stage_store(1);
+  if (DMA) {
+    stage_dma(0, 0);
+    stage_dma(1, 1);
+  } else {
+    stage_load(0);
+    stage_store(0);
+    stage_load(1);
+    stage_store(1);
+  }
   __syncthreads();
 
   int blk0 = 0;  // it % 3
@@ -218,7 +252,9 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
     const bool pf = (it + 1 < niter);
     const int blk1 = (blk0 == 2) ? 0 : blk0 + 1;
     const int blk2 = (blk1 == 2) ? 0 : blk1 + 1;
-    if (pf) stage_load(it + 2);
+    if (pf) {
+      if (DMA) stage_dma(it + 2, blk2); else stage_load(it + 2);
+    }
 
 #pragma unroll
     for (int uu = 0; uu < C::UPW; ++uu) {
@@ -228,13 +264,15 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
       if (ACCIN) {
-        const int t0i = BR * it + 2 * rp;
+        const int t0i = BR * it + 2 * rp, cb = f0 + 32 * m + 4 * h;
+        const float* i0 = a.acc_in + (((size_t)b * H + t0i) * W + cb) * COUT + n;
+        const int rowstride = W * COUT;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int f = f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (f < W) {
-            if (t0i < H) acc0[i] = a.acc_in[(((size_t)b * H + t0i) * W + f) * COUT + n];
-            if (t0i + 1 < H) acc1[i] = a.acc_in[(((size_t)b * H + t0i + 1) * W + f) * COUT + n];
+          const int dcol = (i & 3) + 8 * (i >> 2);
+          if (cb + dcol < W) {
+            if (t0i < H) acc0[i] = i0[dcol * COUT];
+            if (t0i + 1 < H) acc1[i] = i0[rowstride + dcol * COUT];
           }
         }
       }
@@ -257,29 +295,31 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         }
       }
 
-      // ---- fused epilogue: + folded bias, ReLU, pool / time-sum
+      // ---- fused epilogue: + folded bias, ReLU, pool / time-sum.  Register i of the accumulator is pixel column
+      // colbase + dcol(i), dcol(i) = (i&3) + 8*(i>>2); addresses are one per-lane base pointer + scalar offsets.
       const int t0 = BR * it + 2 * rp;  // pre-pool rows t0, t0+1
+      const int colbase = f0 + 32 * m + 4 * h;
       if (EPI == EPI_POOL_H2) {
         const int Ho = H >> 1, to = t0 >> 1;
-        T* out = (T*)a.out;
         if (to < Ho) {
+          T* o0 = (T*)a.out + (((size_t)b * Ho + to) * W + colbase) * COUT + n;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int f = f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int dcol = (i & 3) + 8 * (i >> 2);
             const float v = 0.5f * (fmaxf(acc0[i] + bv, 0.f) + fmaxf(acc1[i] + bv, 0.f));
-            if (f < W) out[(((size_t)b * Ho + to) * W + f) * COUT + n] = cvt_out<T>(v);
+            if (colbase + dcol < W) o0[dcol * COUT] = cvt_out<T>(v);
           }
         }
       } else if (EPI == EPI_POOL_2X2) {
         const int Ho = H >> 1, Wo = W >> 1, to = t0 >> 1;
-        T* out = (T*)a.out;
         if (to < Ho) {
+          T* o0 = (T*)a.out + (((size_t)b * Ho + to) * Wo + (colbase >> 1)) * COUT + n;
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
-            const int fo = (f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h) >> 1;
+            const int dfo = ((i & 3) + 8 * (i >> 2)) >> 1;
             const float v = 0.25f * (fmaxf(acc0[i] + bv, 0.f) + fmaxf(acc0[i + 1] + bv, 0.f) +
                                      fmaxf(acc1[i] + bv, 0.f) + fmaxf(acc1[i + 1] + bv, 0.f));
-            if (fo < Wo) out[(((size_t)b * Ho + to) * Wo + fo) * COUT + n] = cvt_out<T>(v);
+            if ((colbase >> 1) + dfo < Wo) o0[dfo * COUT] = cvt_out<T>(v);
           }
         }
       } else if (EPI == EPI_MEAN_T) {
@@ -292,34 +332,56 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
               cs[mm][i] += k0 * fmaxf(acc0[i] + bv, 0.f) + k1 * fmaxf(acc1[i] + bv, 0.f);
           }
       } else if (EPI == EPI_RAW) {
+        float* o0 = a.raw_out + (((size_t)b * H + t0) * W + colbase) * COUT + n;
+        const int rowstride = W * COUT;
+        const bool r0ok = t0 < H, r1ok = t0 + 1 < H;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int f = f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (f < W) {
-            if (t0 < H) a.raw_out[(((size_t)b * H + t0) * W + f) * COUT + n] = acc0[i];
-            if (t0 + 1 < H) a.raw_out[(((size_t)b * H + t0 + 1) * W + f) * COUT + n] = acc1[i];
+          const int dcol = (i & 3) + 8 * (i >> 2);
+          if (colbase + dcol < W) {
+            if (r0ok) o0[dcol * COUT] = acc0[i];
+            if (r1ok) o0[rowstride + dcol * COUT] = acc1[i];
           }
         }
       } else {  // EPI_PLAIN
-        T* out = (T*)a.out;
+        T* o0 = (T*)a.out + (((size_t)b * H + t0) * W + colbase) * COUT + n;
+        const int rowstride = W * COUT;
+        const bool r0ok = t0 < H, r1ok = t0 + 1 < H;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int f = f0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int dcol = (i & 3) + 8 * (i >> 2);
           float v0 = acc0[i] + bv, v1 = acc1[i] + bv;
           if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          if (f < W) {
-            if (t0 < H) out[(((size_t)b * H + t0) * W + f) * COUT + n] = cvt_out<T>(v0);
-            if (t0 + 1 < H) out[(((size_t)b * H + t0 + 1) * W + f) * COUT + n] = cvt_out<T>(v1);
+          if (colbase + dcol < W) {
+            if (r0ok) { o0[dcol * COUT] = cvt_out<T>(v0); st1 += v0; st2 = fmaf(v0, v0, st2); }
+            if (r1ok) { o0[rowstride + dcol * COUT] = cvt_out<T>(v1); st1 += v1; st2 = fmaf(v1, v1, st2); }
           }
         }
       }
     }
 
-    if (pf) stage_store(blk2);
+    if (pf && !DMA) stage_store(blk2);
     __syncthreads();
     blk0 = blk1;
   }
 
+  if (EPI == EPI_PLAIN) {
+    if (a.stats_partial) {  // lanes r and r+32 hold the same channel; M-group waves too: combine through LDS
+      st1 += __shfl_xor(st1, 32, 64);
+      st2 += __shfl_xor(st2, 32, 64);
+      float* red = (float*)smem;
+      if (h == 0) { red[((mg * NSL + nsl) * 32 + r) * 2] = st1; red[((mg * NSL + nsl) * 32 + r) * 2 + 1] = st2; }
+      __syncthreads();
+      if (tid < NSL * 32) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < MG; ++g) { s1 += red[(g * NSL * 32 + tid) * 2]; s2 += red[(g * NSL * 32 + tid) * 2 + 1]; }
+        float* dst = a.stats_partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * (NSL * 32) + tid) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
   if (EPI == EPI_MEAN_T) {
     // column sums -> LDS [channel][column] (ring is free after the last barrier) -> coalesced rows of emb
     float* ef = (float*)smem;
@@ -339,12 +401,12 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
 }
 
 // host-side launcher (defined per instantiation in conv3x3_inst_*.hip)
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false>
+template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false>
 hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<T, CIN, NSL, MG, RP, MT, EPI>;
   ConvArgs a = a0;
   a.nstrips = (a.W + 32 * MT - 1) / (32 * MT);
-  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN>;
+  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN, DMA>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

@@ -6,10 +6,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/dfa_hip.h"
 #include "conv3x3_mfma.h"
+#include "rng.h"
 
 namespace dfa {
 
@@ -39,6 +41,12 @@ struct Cnn2dState {
   float* w1 = nullptr;     // [32][9] folded
   float* b1 = nullptr;     // [32]
   PackedConv c2, c3;
+  // train mode (train_api.hip)
+  void* train_packed = nullptr;
+  float *tw1 = nullptr, *tb1 = nullptr;   // conv1 folded with the current batch statistics
+  PackedConv t2, t3, d2, d3;              // raw forward images and data-gradient images
+  DropCfg train_drop{};
+  int train_prec = -1, train_B = 0, train_T = 0;
 };
 
 struct Cnn1dState {
@@ -66,6 +74,8 @@ struct dfa_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   char err[512] = {0};
+  void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
+  int conv_dma = 0;            // stage conv inputs with global_load_lds (1) or through registers (0)
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
   dfa::CaeState cae;
@@ -122,13 +132,16 @@ hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, con
                              const float* var, float* w1, float* b1, int cout, hipStream_t s);
 hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
                                     const float* mean, const float* var, int cin_total, int cin_off, int cin, int cout,
-                                    int prec, uint4* wpack, float* bias, hipStream_t s);
+                                    int prec, uint4* wpack, float* bias, hipStream_t s, int fold = 1);
+hipError_t launch_pack_conv3x3_dgrad(const float* w, int cin, int cout, int co_off, int co_n, int prec, uint4* wpack,
+                                     float* bias, hipStream_t s);
 hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float* g, const float* beta,
                                      const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
                                      float* bias, hipStream_t s);
 // conv1.hip
 hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
-                        const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s);
+                        const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s,
+                        const DropCfg* drop = nullptr);
 // linear.hip
 hipError_t launch_linear(const float* emb, const float* w, const float* bias, float* logits, int B, int K,
                          hipStream_t s);
@@ -147,9 +160,37 @@ hipError_t launch_cae_dec4_mse(const void* d3, int prec, const float* w4, const 
                                int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon,
                                float* partial, float* mse, int B, int H3, int W3, int T, int F, hipStream_t s);
 hipError_t launch_cae_latent_export(const void* lat, int prec, float* out, int B, int HW, int C, hipStream_t s);
+// train_elem.hip / train_conv1.hip / wgrad_mfma.hip
+hipError_t launch_bn_finalize(const float* partial, int nparts, int C, double n, float* mean, float* var, float* invstd,
+                              float* running_mean, float* running_var, float momentum, hipStream_t s);
+hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s);
+hipError_t launch_reduce_partials_strided(const float* partial, int nparts, int stride, int off, int n, float* out,
+                                          hipStream_t s);
+hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, void* out, int B, int H, int W, int C, const DropCfg& dc,
+                                    hipStream_t s);
+hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
+                             int B, int K, hipStream_t s);
+int bn_bwd_blocks(int B, int H, int W, int* pix_per_block);
+hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s);
+hipError_t launch_bce_smooth(const float* logits, const float* labels, float eps, int B, float* loss, float* dlogits,
+                             hipStream_t s);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                        float wd, int step, float grad_scale, hipStream_t s);
+int conv1_train_blocks(int B, int T, int F);
+hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
+                              const float* bconv, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
+                              int T, int F, const DropCfg& dc, hipStream_t s);
+hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
+                           float* db, int B, int H, int W, int nwg, hipStream_t s);
 // conv3x3_inst_*.hip
-hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s);
-hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = 0);
+hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = 0);
 struct ConvTArgs;
 hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s);

@@ -32,15 +32,16 @@ __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const floa
                                          const float* __restrict__ g, const float* __restrict__ beta,
                                          const float* __restrict__ mean, const float* __restrict__ var,
                                          int cin_total, int cin_off, int cin, int cout, uint4* __restrict__ wpack,
-                                         float* __restrict__ bias) {
+                                         float* __restrict__ bias, int fold) {
   constexpr int KG = 32 / (int)sizeof(T);
   constexpr int EPL = KG / 2;  // elements per lane per k-group
   const int nkg = cin / KG;
   const int total = (cout / 32) * 9 * nkg * 64;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cout) {
-    const float s = g[i] / sqrtf(var[i] + kBnEps);
-    bias[i] = (b[i] - mean[i]) * s + beta[i];
+    // fold == 0: raw convolution (train mode: BN uses batch statistics and runs as its own pass)
+    const float s = fold ? g[i] / sqrtf(var[i] + kBnEps) : 1.f;
+    bias[i] = fold ? (b[i] - mean[i]) * s + beta[i] : b[i];
   }
   if (i >= total) return;
   const int lane = i & 63;
@@ -50,7 +51,7 @@ __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const floa
   const int tap = rest % 9;
   const int slice = rest / 9;
   const int co = slice * 32 + (lane & 31), hh = lane >> 5;
-  const float s = g[co] / sqrtf(var[co] + kBnEps);
+  const float s = fold ? g[co] / sqrtf(var[co] + kBnEps) : 1.f;
   T v[EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
@@ -70,17 +71,17 @@ hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, con
 
 hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
                                     const float* mean, const float* var, int cin_total, int cin_off, int cin, int cout,
-                                    int prec, uint4* wpack, float* bias, hipStream_t s) {
+                                    int prec, uint4* wpack, float* bias, hipStream_t s, int fold) {
   const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
   int total = (cout / 32) * 9 * (cin / kg) * 64;
   if (total < cout) total = cout;
   dim3 grid((total + 255) / 256), block(256);
   if (prec == DFA_PREC_BF16)
     hipLaunchKernelGGL(fold_pack_conv3x3_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin_total, cin_off,
-                       cin, cout, wpack, bias);
+                       cin, cout, wpack, bias, fold);
   else
     hipLaunchKernelGGL(fold_pack_conv3x3_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin_total, cin_off, cin,
-                       cout, wpack, bias);
+                       cout, wpack, bias, fold);
   return hipGetLastError();
 }
 
@@ -127,6 +128,48 @@ hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float
   else
     hipLaunchKernelGGL(fold_pack_convt2x2_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
                        bias);
+  return hipGetLastError();
+}
+
+// data-gradient ("dgrad") image of a 3x3 / pad 1 convolution: da = conv3x3(dz, W') with
+//   W'[ci][co][dy'][dx'] = W[co][ci][2-dy'][2-dx']     (input channels = the forward conv's output channels).
+// Packed like a forward conv with CIN' = cout window [co_off, co_off+co_n), COUT' = cin; no bias, no BN.
+template <typename T>
+__global__ void pack_conv3x3_dgrad_kernel(const float* __restrict__ w, int cin, int cout, int co_off, int co_n,
+                                          uint4* __restrict__ wpack, float* __restrict__ bias) {
+  constexpr int KG = 32 / (int)sizeof(T);
+  constexpr int EPL = KG / 2;
+  const int nkg = co_n / KG;
+  const int total = (cin / 32) * 9 * nkg * 64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cin) bias[i] = 0.f;
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int kg = rest % nkg;
+  rest /= nkg;
+  const int tap = rest % 9;
+  const int slice = rest / 9;
+  const int ci = slice * 32 + (lane & 31), hh = lane >> 5;
+  T v[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int co = co_off + KG * kg + EPL * hh + j;
+    v[j] = cvt_out<T>(w[((size_t)co * cin + ci) * 9 + (8 - tap)]);
+  }
+  wpack[i] = *reinterpret_cast<const uint4*>(v);
+}
+
+hipError_t launch_pack_conv3x3_dgrad(const float* w, int cin, int cout, int co_off, int co_n, int prec, uint4* wpack,
+                                     float* bias, hipStream_t s) {
+  const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
+  int total = (cin / 32) * 9 * (co_n / kg) * 64;
+  if (total < cin) total = cin;
+  dim3 grid((total + 255) / 256), block(256);
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_dgrad_kernel<bf16_t>, grid, block, 0, s, w, cin, cout, co_off, co_n, wpack, bias);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_dgrad_kernel<float>, grid, block, 0, s, w, cin, cout, co_off, co_n, wpack, bias);
   return hipGetLastError();
 }
 

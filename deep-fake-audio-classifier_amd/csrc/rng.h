@@ -1,0 +1,46 @@
+// rng.h -- counter-based Philox4x32-10 for the dropout masks (src/model.py:19,25 nn.Dropout in train mode).
+// The mask of element `idx` of dropout layer `layer` is a pure function of (seed, offset, layer, idx), so the backward
+// pass regenerates it instead of storing it.  torch's CPU generator stream cannot be reproduced on a GPU; parity for
+// training is exact only with dropout = 0 and statistical otherwise (SURVEY.md section 7 "hard parts").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfa {
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
+struct DropCfg {
+  unsigned thresh;   // drop when r < thresh (thresh = p * 2^32); 0 disables dropout
+  float scale;       // 1 / (1 - p)
+  uint64_t seed, offset;
+  unsigned layer;
+};
+
+// keep-scale factors (0 or scale) of 8 consecutive elements starting at idx (idx % 8 == 0)
+__device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, float* f) {
+  if (d.thresh == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 1.f;
+    return;
+  }
+  const uint64_t q = (idx >> 2) + d.offset;
+  const uint2 key = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
+  const uint4 r0 = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
+  const uint4 r1 = philox4x32_10(make_uint4((unsigned)(q + 1), (unsigned)((q + 1) >> 32), d.layer, 0u), key);
+  const unsigned r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (r[j] < d.thresh) ? 0.f : d.scale;
+}
+
+}  // namespace dfa

@@ -1,0 +1,274 @@
+// train_api.hip -- C ABI of the CNN2D training step (replaces, for src/train.py:71-76, what torch autograd does
+// with src/model.py:13-39 in train mode):
+//   dfa_cnn2d_forward_train : conv -> BatchNorm(batch statistics, running-stat update) -> ReLU -> AvgPool -> Dropout x2,
+//                             conv -> BN -> ReLU -> mean_T -> Linear, keeping what backward needs in the workspace
+//   dfa_cnn2d_backward      : gradients of all 14 parameters from dlogits (in parameters() order)
+//   dfa_bce_smooth_fwd_bwd  : BCEWithLogitsLoss(mean) on smoothed labels + dlogits      (src/train.py:311-320)
+//   dfa_adamw_step          : torch.optim.AdamW update of one flat fp32 buffer           (src/train.py:326-328)
+#include "dfa_internal.h"
+
+using namespace dfa;
+
+namespace dfa {
+hipError_t launch_train_fwd2(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_train_fwd3(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_train_dgrad2(int prec, const ConvArgs& a, hipStream_t s);
+enum { C1M_STATS = 0, C1M_BWD_REDUCE = 1, C1M_WGRAD = 2 };
+enum { SRC_MEANT = 0, SRC_POOL = 1 };
+
+// dgamma = S2, dbeta = S1 from sums[C][2]
+__global__ void split_sums_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                  int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { dbeta[c] = sums[2 * c]; dgamma[c] = sums[2 * c + 1]; }
+}
+// conv1 weight-gradient record [32][10] -> dW1[32][9], db1[32]
+__global__ void split_c1_kernel(const float* __restrict__ rec, float* __restrict__ dw, float* __restrict__ db) {
+  const int i = threadIdx.x;  // 320 threads
+  const int c = i / 10, j = i - c * 10;
+  if (j < 9) dw[c * 9 + j] = rec[i]; else db[c] = rec[i];
+}
+}  // namespace dfa
+
+namespace {
+
+inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+constexpr int kWgradWGs = 256;
+
+struct TrainPlan {
+  int H1, H2;
+  size_t a1, z2, a2, z3, emb, demb, dz3, da2, dz2, da1, raw, stats, sums, partial, partial_bytes, total;
+};
+
+TrainPlan plan_train(int B, int T, int F, int prec) {
+  TrainPlan p;
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  p.H1 = T / 2;
+  p.H2 = p.H1 / 2;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
+  p.a1 = take((size_t)B * p.H1 * F * 32 * es);
+  p.z2 = take((size_t)B * p.H1 * F * 64 * es);
+  p.a2 = take((size_t)B * p.H2 * F * 64 * es);
+  p.z3 = take((size_t)B * p.H2 * F * 128 * es);
+  p.emb = take((size_t)B * 128 * F * 4);
+  p.demb = take((size_t)B * 128 * F * 4);
+  p.dz3 = take((size_t)B * p.H2 * F * 128 * es);
+  p.da2 = take((size_t)B * p.H2 * F * 64 * es);
+  p.dz2 = take((size_t)B * p.H1 * F * 64 * es);
+  p.da1 = take((size_t)B * p.H1 * F * 32 * es);
+  p.raw = take(prec == DFA_PREC_F32 ? (size_t)B * p.H2 * F * 64 * 4 : 0);
+  p.stats = take((32 + 64 + 128) * 3 * 4);          // mean | var | invstd per layer
+  p.sums = take((32 + 64 + 128) * 2 * 4 + 320 * 4);  // (S1,S2) per layer + conv1 wgrad record
+  const int nstrips = (F + 31) / 32;
+  size_t pb = (size_t)B * nstrips * 128 * 2 * 4;                              // conv stats partials
+  pb = std::max(pb, (size_t)conv1_train_blocks(B, T, F) * 320 * 4);          // conv1 passes
+  int ppb;
+  pb = std::max(pb, (size_t)bn_bwd_blocks(B, p.H1, F, &ppb) * 128 * 2 * 4);  // BN backward partials
+  pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 128) * 4);   // weight-gradient partials
+  p.partial_bytes = pb;
+  p.partial = take(pb);
+  p.total = off;
+  return p;
+}
+
+struct StatPtrs { float *mean, *var, *invstd; };
+StatPtrs stat_ptrs(char* ws, const TrainPlan& pl, int layer) {
+  const int off[3] = {0, 32, 96}, C[3] = {32, 64, 128};
+  float* base = (float*)(ws + pl.stats);
+  float* l = base + 3 * off[layer];
+  return {l, l + C[layer], l + 2 * C[layer]};
+}
+float* sums_ptr(char* ws, const TrainPlan& pl, int layer) {
+  const int off[3] = {0, 32, 96};
+  return (float*)(ws + pl.sums) + 2 * off[layer];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dfa_cnn2d_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F, int precision) {
+  (void)ctx;
+  if (B < 1 || T < 4 || F < 1) return 0;
+  return plan_train(B, T, F, precision).total;
+}
+
+int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                            int64_t stride_t, int64_t stride_f, int precision, float p_drop, uint64_t seed,
+                            uint64_t offset, float momentum, int update_running_stats, float* logits, float* embedding,
+                            void* workspace, size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn2dState& m = ctx->cnn2d;
+  if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_set_params has not been called");
+  if (!x || !logits || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, logits and workspace must be non-null");
+  if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
+  if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
+  if (B < 1 || T < 4) return fail(ctx, DFA_E_BAD_SHAPE, "need B >= 1 and T >= 4 (got %d, %d)", B, T);
+  if (F != m.in_features) return fail(ctx, DFA_E_BAD_SHAPE, "feature dim %d does not match in_features=%d", F, m.in_features);
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(ctx, DFA_E_BAD_SHAPE, "dropout p must be in [0, 1)");
+  const TrainPlan pl = plan_train(B, T, F, precision);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  if (((uintptr_t)workspace & 255) != 0) return fail(ctx, DFA_E_WORKSPACE, "workspace must be 256-byte aligned");
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // train-mode weight images: raw convs (BN is its own pass) + data-gradient images; rebuilt every step (weights move)
+  if (!m.train_packed) {
+    const size_t w2 = (size_t)64 * 32 * 9 * 4, w3 = (size_t)128 * 64 * 9 * 4;
+    const size_t need = al((288 + 32 + 64 + 128 + 32 + 64) * 4) + 2 * (w2 + w3);
+    DFA_HIP_CHECK(ctx, hipMalloc(&m.train_packed, need));
+    char* base = (char*)m.train_packed;
+    m.tw1 = (float*)base; m.tb1 = m.tw1 + 288;
+    m.t2.bias = m.tb1 + 32; m.t3.bias = m.t2.bias + 64;
+    m.d2.bias = m.t3.bias + 128; m.d3.bias = m.d2.bias + 32;
+    char* wp = base + al((288 + 32 + 64 + 128 + 32 + 64) * 4);
+    m.t2.wpack = (uint4*)wp; wp += w2;
+    m.t3.wpack = (uint4*)wp; wp += w3;
+    m.d2.wpack = (uint4*)wp; wp += w2;
+    m.d3.wpack = (uint4*)wp;
+  }
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  const int prec = precision;
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], nullptr, nullptr, nullptr, nullptr, 32, 0, 32, 64, prec, m.t2.wpack, m.t2.bias, s, 0));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 0, 64, 128, prec, m.t3.wpack, m.t3.bias, s, 0));
+  DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[6], 32, 64, 0, 64, prec, m.d2.wpack, m.d2.bias, s));
+  if (prec == DFA_PREC_BF16) {
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 0, 128, prec, m.d3.wpack, m.d3.bias, s));
+  } else {
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 0, 64, prec, m.d3.wpack, m.d3.bias, s));
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64, 64, prec, m.d3.wpack + (size_t)(64 / 32) * 9 * 8 * 64, m.d3.bias, s));
+  }
+  char* ws = (char*)workspace;
+  float* partial = (float*)(ws + pl.partial);
+  DropCfg dc{};
+  dc.thresh = (p_drop > 0.f) ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  dc.scale = 1.0f / (1.0f - p_drop);
+  dc.seed = seed; dc.offset = offset;
+  m.train_drop = dc; m.train_prec = prec; m.train_B = B; m.train_T = T;
+  float* rm[3] = {nullptr, nullptr, nullptr}; float* rv[3] = {nullptr, nullptr, nullptr};
+  if (update_running_stats) {
+    rm[0] = (float*)p[4]; rv[0] = (float*)p[5]; rm[1] = (float*)p[10]; rv[1] = (float*)p[11];
+    rm[2] = (float*)p[16]; rv[2] = (float*)p[17];
+  }
+  // ---- block 1
+  StatPtrs s1 = stat_ptrs(ws, pl, 0);
+  DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, prec, partial, B, T, F, dc, s));
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, s));
+  DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], s1.mean, s1.var, m.tw1, m.tb1, 32, s));
+  dc.layer = 1;
+  DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.tw1, m.tb1, ws + pl.a1, prec, B, T, F, s, &dc));
+  // ---- block 2
+  const int nstrips = (F + 31) / 32;
+  {
+    ConvArgs a{};
+    a.in = ws + pl.a1; a.wpack = m.t2.wpack; a.bias = m.t2.bias; a.out = ws + pl.z2;
+    a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.relu = 0; a.stats_partial = partial; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_train_fwd2(prec, a, s));
+  }
+  StatPtrs s2 = stat_ptrs(ws, pl, 1);
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * nstrips, 64, (double)B * pl.H1 * F, s2.mean, s2.var, s2.invstd, rm[1], rv[1], momentum, s));
+  dc.layer = 2;
+  DFA_HIP_CHECK(ctx, launch_bn_relu_pool_drop(prec, ws + pl.z2, s2.mean, s2.invstd, p[8], p[9], ws + pl.a2, B, pl.H1, F, 64, dc, s));
+  // ---- block 3
+  {
+    ConvArgs a{};
+    a.in = ws + pl.a2; a.wpack = m.t3.wpack; a.bias = m.t3.bias; a.out = ws + pl.z3;
+    a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.relu = 0; a.stats_partial = partial; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_train_fwd3(prec, a, s));
+  }
+  StatPtrs s3 = stat_ptrs(ws, pl, 2);
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * nstrips, 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, s));
+  float* emb = (float*)(ws + pl.emb);
+  DFA_HIP_CHECK(ctx, launch_bn_relu_meant(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], emb, B, pl.H2, F, 128, s));
+  if (embedding) DFA_HIP_CHECK(ctx, hipMemcpyAsync(embedding, emb, (size_t)B * 128 * F * 4, hipMemcpyDeviceToDevice, s));
+  DFA_HIP_CHECK(ctx, launch_linear(emb, p[18], p[19], logits, B, 128 * F, s));
+  return DFA_OK;
+}
+
+int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                       int64_t stride_f, const float* dlogits, float* const* grads, int ngrads, void* workspace,
+                       size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn2dState& m = ctx->cnn2d;
+  if (!m.train_packed || m.train_B != B || m.train_T != T)
+    return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_backward must follow dfa_cnn2d_forward_train on the same batch");
+  if (!x || !dlogits || !grads || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, dlogits, grads and workspace must be non-null");
+  if (ngrads != 14) return fail(ctx, DFA_E_BAD_SHAPE, "cnn2d has 14 parameters, got %d gradient pointers", ngrads);
+  for (int i = 0; i < 14; ++i)
+    if (!grads[i]) return fail(ctx, DFA_E_NULL_PTR, "gradient pointer %d is null", i);
+  const int prec = m.train_prec;
+  const TrainPlan pl = plan_train(B, T, F, prec);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small");
+  char* ws = (char*)workspace;
+  float* partial = (float*)(ws + pl.partial);
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  DropCfg dc = m.train_drop;
+  StatPtrs s1 = stat_ptrs(ws, pl, 0), s2 = stat_ptrs(ws, pl, 1), s3 = stat_ptrs(ws, pl, 2);
+  float *sm1 = sums_ptr(ws, pl, 0), *sm2 = sums_ptr(ws, pl, 1), *sm3 = sums_ptr(ws, pl, 2);
+  float* c1rec = (float*)(ws + pl.sums) + 2 * (32 + 64 + 128);
+  float* demb = (float*)(ws + pl.demb);
+  // classifier
+  DFA_HIP_CHECK(ctx, launch_linear_bwd(dlogits, p[18], (const float*)(ws + pl.emb), demb, grads[12], grads[13], B, 128 * F, s));
+  // block 3: BN backward (upstream = mean_T then Linear), weight gradient, data gradient
+  DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_MEANT, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], demb, nullptr, partial, sm3, ws + pl.dz3,
+                                   B, pl.H2, F, 128, dc, s));
+  hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm3, grads[10], grads[11], 128);
+  DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, 64, 128, ws + pl.dz3, ws + pl.a2, partial, grads[8], grads[9], B, pl.H2, F, kWgradWGs, s));
+  {
+    ConvArgs a{};
+    a.in = ws + pl.dz3; a.wpack = m.d3.wpack; a.bias = m.d3.bias; a.out = ws + pl.da2;
+    a.B = B; a.H = pl.H2; a.W = F; a.COUT = 64; a.relu = 0; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s));
+  }
+  // block 2
+  dc.layer = 2;
+  DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL, ws + pl.z2, s2.mean, s2.invstd, p[8], p[9], nullptr, ws + pl.da2, partial, sm2, ws + pl.dz2,
+                                   B, pl.H1, F, 64, dc, s));
+  hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm2, grads[6], grads[7], 64);
+  DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, 32, 64, ws + pl.dz2, ws + pl.a1, partial, grads[4], grads[5], B, pl.H1, F, kWgradWGs, s));
+  {
+    ConvArgs a{};
+    a.in = ws + pl.dz2; a.wpack = m.d2.wpack; a.bias = m.d2.bias; a.out = ws + pl.da1;
+    a.B = B; a.H = pl.H1; a.W = F; a.COUT = 32; a.relu = 0; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_train_dgrad2(prec, a, s));
+  }
+  // block 1 (z1 recomputed from x)
+  dc.layer = 1;
+  const int nb1 = conv1_train_blocks(B, T, F);
+  DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
+                                        nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s));
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm1, s));
+  hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm1, grads[2], grads[3], 32);
+  DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_WGRAD, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
+                                        sm1, ws + pl.da1, prec, partial, B, T, F, dc, s));
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, c1rec, s));
+  hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, c1rec, grads[0], grads[1]);
+  DFA_HIP_CHECK(ctx, hipGetLastError());
+  return DFA_OK;
+}
+
+int dfa_bce_smooth_fwd_bwd(dfa_ctx* ctx, const float* logits, const float* labels, float label_smoothing, int B,
+                           float* loss, float* dlogits) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  if (!logits || !labels) return fail(ctx, DFA_E_NULL_PTR, "logits and labels must be non-null");
+  if (!(label_smoothing >= 0.f && label_smoothing < 0.5f))
+    return fail(ctx, DFA_E_BAD_SHAPE, "--label-smoothing must be in [0, 0.5)");   /* src/train.py:308-309 */
+  if (B < 1) return fail(ctx, DFA_E_BAD_SHAPE, "B must be >= 1");
+  DFA_HIP_CHECK(ctx, launch_bce_smooth(logits, labels, label_smoothing, B, loss, dlogits, ctx->stream));
+  return DFA_OK;
+}
+
+int dfa_adamw_step(dfa_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(ctx, DFA_E_NULL_PTR, "adamw buffers must be non-null");
+  if (step < 1) return fail(ctx, DFA_E_BAD_SHAPE, "step is 1-based (got %d)", step);
+  if (n == 0) return DFA_OK;
+  DFA_HIP_CHECK(ctx, launch_adamw(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ctx->stream));
+  return DFA_OK;
+}
+
+}  // extern "C"

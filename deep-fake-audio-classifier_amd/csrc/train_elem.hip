@@ -1,0 +1,421 @@
+// train_elem.hip -- train-mode passes of the 2-D CNN that are not convolutions (src/train.py:71-76 through
+// src/model.py:16-19,22-25,28-29,37-39 and torch autograd): BatchNorm with batch statistics (forward + backward),
+// ReLU, AvgPool2d((2,1)), Dropout, mean over T, Linear backward, BCE-with-logits on smoothed labels, AdamW.
+// All tensors are channels-last [B][H][W][C]; every pass is HBM-bound and moves 8 channels (16-32 bytes) per lane.
+// Reductions are two-stage with a fixed order (per-block partials in fp32, final sum in fp64): deterministic.
+#include "dfa_internal.h"
+#include "rng.h"
+
+namespace dfa {
+
+template <typename T>
+__device__ __forceinline__ void ld8(const T* p, float* v);
+template <>
+__device__ __forceinline__ void ld8<float>(const float* p, float* v) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float* v) {
+  const uint4 q = *reinterpret_cast<const uint4*>(p);
+  const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(u[e] << 16); v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void st8<float>(float* p, const float* v) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float* v) {
+  bf16_t o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = float_to_bf16(v[j]);
+  *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(o);
+}
+
+// ---- BatchNorm statistics: partial[k][C][2] (sum, sum of squares) -> mean, biased var, invstd; running stats update
+// (torch.nn.BatchNorm2d train mode: running = (1-m)*running + m*batch, with the UNBIASED batch variance).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C, double n,
+                                                          float* __restrict__ mean, float* __restrict__ var,
+                                                          float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = tid; k < nparts; k += 256) {
+    s1 += (double)partial[((size_t)k * C + c) * 2];
+    s2 += (double)partial[((size_t)k * C + c) * 2 + 1];
+  }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { r1[tid] += r1[tid + off]; r2[tid] += r2[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double m = r1[0] / n;
+    double v = r2[0] / n - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+    invstd[c] = (float)(1.0 / sqrt(v + (double)kBnEps));
+    if (running_mean) {
+      const double vu = (n > 1.0) ? v * n / (n - 1.0) : v;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * vu);
+    }
+  }
+}
+
+// generic fixed-order reduction of partial[k][n] over k (fp64 accumulate), out[j] = scale * sum
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int n, float scale,
+                                       float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nparts; ++k) s += (double)partial[(size_t)k * n + j];
+  out[j] = (float)(s * (double)scale);
+}
+
+// out[j] = sum_k partial[k*stride + off + j]
+__global__ void reduce_partials_strided_kernel(const float* __restrict__ partial, int nparts, int stride, int off, int n,
+                                               float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nparts; ++k) s += (double)partial[(size_t)k * stride + off + j];
+  out[j] = (float)s;
+}
+
+// ---- forward: BN(batch stats) + ReLU + AvgPool2d((2,1)) + Dropout        z[B][H][W][C] -> a[B][H/2][W][C]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_poolh2_drop_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, T* __restrict__ out,
+                                                                  int B, int H, int W, int C, DropCfg dc) {
+  const int Ho = H >> 1, CG = C >> 3;
+  const size_t total = (size_t)B * Ho * W * CG;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const size_t pix = i / CG;                 // (b*Ho + to)*W + f
+  const int f = (int)(pix % W);
+  const size_t bt = pix / W;
+  const int to = (int)(bt % Ho), b = (int)(bt / Ho);
+  float z0[8], z1[8], o[8], ds[8];
+  ld8<T>(z + ((((size_t)b * H + 2 * to) * W + f) * C + cg * 8), z0);
+  ld8<T>(z + ((((size_t)b * H + 2 * to + 1) * W + f) * C + cg * 8), z1);
+  drop_scale8(dc, pix * C + cg * 8, ds);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    o[j] = 0.5f * (fmaxf(fmaf(z0[j], sc, sh), 0.f) + fmaxf(fmaf(z1[j], sc, sh), 0.f)) * ds[j];
+  }
+  st8<T>(out + pix * C + cg * 8, o);
+}
+
+// ---- forward: BN(batch stats) + ReLU + mean over T       z[B][H][W][C] -> emb[B][C][W]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ emb,
+                                                            int B, int H, int W, int C) {
+  const int CG = C >> 3;
+  const size_t total = (size_t)B * W * CG;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const int f = (int)((i / CG) % W), b = (int)(i / ((size_t)CG * W));
+  float sc[8], sh[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    sc[j] = gamma[c] * invstd[c];
+    sh[j] = beta[c] - mean[c] * sc[j];
+    acc[j] = 0.f;
+  }
+  for (int t = 0; t < H; ++t) {
+    float v[8];
+    ld8<T>(z + ((((size_t)b * H + t) * W + f) * C + cg * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+  }
+  const float inv_h = 1.0f / (float)H;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) emb[((size_t)b * C + cg * 8 + j) * W + f] = acc[j] * inv_h;
+}
+
+// ---- backward of Linear(K,1): demb[b][j] = dlogit[b]*w[j];  dw[j] = sum_b dlogit[b]*emb[b][j];  db = sum_b dlogit[b]
+__global__ void linear_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
+                                  const float* __restrict__ emb, float* __restrict__ demb, float* __restrict__ dw,
+                                  float* __restrict__ db, int B, int K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[b];
+    db[0] = s;
+  }
+  if (j >= K) return;
+  const float wj = w[j];
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dlogits[b];
+    demb[(size_t)b * K + j] = d * wj;
+    s = fmaf(d, emb[(size_t)b * K + j], s);
+  }
+  dw[j] = s;
+}
+
+// ---- BatchNorm backward.  Upstream gradient dy of the BN *output* y = gamma*xhat+beta after the ReLU mask:
+//   SRC_MEANT: dy = (y > 0) * demb[b][c][f] / H                                   (block 3: mean over T then Linear)
+//   SRC_POOL : dy = (y > 0) * 0.5 * dropscale * da[b][t/2][f][c], rows t >= 2*(H/2) get 0   (blocks 1, 2)
+// reduce: S1[c] = sum dy, S2[c] = sum dy*xhat  (= dbeta, dgamma);  apply: dz = gamma*invstd*(dy - S1/N - xhat*S2/N).
+enum { SRC_MEANT = 0, SRC_POOL = 1 };
+
+template <typename T, int SRC>
+__device__ __forceinline__ void upstream8(const float* demb, const T* da, const DropCfg& dc, int b, int t, int f, int cg,
+                                          int H, int W, int C, float inv_h, float* g) {
+  if (SRC == SRC_MEANT) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = demb[((size_t)b * C + cg * 8 + j) * W + f] * inv_h;
+  } else {
+    const int Ho = H >> 1, to = t >> 1;
+    if (to >= Ho) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = 0.f;
+      return;
+    }
+    const size_t pix = ((size_t)b * Ho + to) * W + f;
+    float d[8], ds[8];
+    ld8<T>(da + pix * C + cg * 8, d);
+    drop_scale8(dc, pix * C + cg * 8, ds);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.5f * ds[j] * d[j];
+  }
+}
+
+template <typename T, int SRC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ demb, const T* __restrict__ da,
+                                                            float* __restrict__ partial, int B, int H, int W, int C,
+                                                            DropCfg dc, int pix_per_block) {
+  extern __shared__ float red[];  // [PL][C][2]
+  const int CG = C >> 3, PL = 256 / CG;
+  const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+  const size_t npix = (size_t)B * H * W;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+  float mu[8], is[8], gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c]; is[j] = invstd[c]; gm[j] = gamma[c]; bt[j] = beta[c];
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  const float inv_h = 1.0f / (float)H;
+  for (size_t p = p0 + pl; p < p1; p += PL) {
+    const int f = (int)(p % W);
+    const size_t bt_ = p / W;
+    const int t = (int)(bt_ % H), b = (int)(bt_ / H);
+    float v[8], g[8];
+    ld8<T>(z + p * C + cg * 8, v);
+    upstream8<T, SRC>(demb, da, dc, b, t, f, cg, H, W, C, inv_h, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mu[j]) * is[j];
+      const float dy = (fmaf(gm[j], xh, bt[j]) > 0.f) ? g[j] : 0.f;
+      s1[j] += dy;
+      s2[j] = fmaf(dy, xh, s2[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[(pl * C + cg * 8 + j) * 2] = s1[j]; red[(pl * C + cg * 8 + j) * 2 + 1] = s2[j]; }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * C * 2 + e];
+    partial[(size_t)blockIdx.x * C * 2 + e] = s;
+  }
+}
+
+template <typename T, int SRC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ sums,
+                                                           const float* __restrict__ demb, const T* __restrict__ da,
+                                                           T* __restrict__ dz, int B, int H, int W, int C, DropCfg dc,
+                                                           float inv_n) {
+  const int CG = C >> 3;
+  const size_t total = (size_t)B * H * W * CG;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const size_t p = i / CG;
+  const int f = (int)(p % W);
+  const size_t bt_ = p / W;
+  const int t = (int)(bt_ % H), b = (int)(bt_ / H);
+  float v[8], g[8], o[8];
+  ld8<T>(z + p * C + cg * 8, v);
+  upstream8<T, SRC>(demb, da, dc, b, t, f, cg, H, W, C, 1.0f / (float)H, g);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    const float xh = (v[j] - mean[c]) * invstd[c];
+    const float dy = (fmaf(gamma[c], xh, beta[c]) > 0.f) ? g[j] : 0.f;
+    o[j] = gamma[c] * invstd[c] * (dy - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+  }
+  st8<T>(dz + p * C + cg * 8, o);
+}
+
+// ---- loss: BCEWithLogitsLoss(mean) on smoothed labels (src/train.py:311-320) + its gradient
+__global__ void bce_smooth_kernel(const float* __restrict__ logits, const float* __restrict__ labels, float eps, int B,
+                                  float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  for (int b = tid; b < B; b += 256) {
+    const float z = logits[b];
+    float y = labels[b];
+    if (eps > 0.f) y = y * (1.0f - eps) + 0.5f * eps;
+    s += (double)(fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))));
+    if (dlogits) dlogits[b] = (1.0f / (1.0f + expf(-z)) - y) / (float)B;
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0 && loss) loss[0] = (float)(red[0] / (double)B);
+}
+
+// ---- optimiser: torch.optim.AdamW step on one flat buffer (decoupled weight decay, bias correction)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float sqrt_bc2, float grad_scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * grad_scale;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+  pi -= (lr / bc1) * (mi / denom);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// ================================================================================================ launchers
+hipError_t launch_bn_finalize(const float* partial, int nparts, int C, double n, float* mean, float* var, float* invstd,
+                              float* running_mean, float* running_var, float momentum, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, partial, nparts, C, n, mean, var, invstd, running_mean,
+                     running_var, momentum);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, n, scale, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials_strided(const float* partial, int nparts, int stride, int off, int n, float* out,
+                                          hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, stride, off,
+                     n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, void* out, int B, int H, int W, int C, const DropCfg& dc,
+                                    hipStream_t s) {
+  const size_t total = (size_t)B * (H / 2) * W * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL(bn_relu_poolh2_drop_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, (bf16_t*)out, B, H, W, C, dc);
+  else
+    hipLaunchKernelGGL(bn_relu_poolh2_drop_kernel<float>, grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, (float*)out, B, H, W, C, dc);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s) {
+  const size_t total = (size_t)B * W * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL(bn_relu_meant_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, emb, B, H, W, C);
+  else
+    hipLaunchKernelGGL(bn_relu_meant_kernel<float>, grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, emb, B, H, W, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
+                             int B, int K, hipStream_t s) {
+  hipLaunchKernelGGL(linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, s, dlogits, w, emb, demb, dw, db, B, K);
+  return hipGetLastError();
+}
+
+int bn_bwd_blocks(int B, int H, int W, int* pix_per_block) {
+  const size_t npix = (size_t)B * H * W;
+  int ppb = 4096;
+  *pix_per_block = ppb;
+  return (int)((npix + ppb - 1) / ppb);
+}
+
+// sums: [C][2] (S1 = dbeta, S2 = dgamma) written by the reduce stage; dz may alias nothing
+hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s) {
+  int ppb;
+  const int nblk = bn_bwd_blocks(B, H, W, &ppb);
+  const int PL = 256 / (C / 8);
+  const size_t lds = (size_t)PL * C * 2 * sizeof(float);
+  const size_t total = (size_t)B * H * W * (C / 8);
+  dim3 g2((unsigned)((total + 255) / 256));
+  const float inv_n = (float)(1.0 / ((double)B * H * W));
+#define DFA_BN_BWD(TT, SRC)                                                                                            \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, SRC>), dim3(nblk), dim3(256), lds, s, (const TT*)z, mean, invstd, gamma, \
+                       beta, demb, (const TT*)da, partial, B, H, W, C, dc, ppb);                                       \
+    hipError_t e = hipGetLastError();                                                                                  \
+    if (e != hipSuccess) return e;                                                                                     \
+    e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s);                                                   \
+    if (e != hipSuccess) return e;                                                                                     \
+    if (dz)                                                                                                            \
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \
+                         demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n);                                        \
+  } while (0)
+  if (prec == DFA_PREC_BF16) {
+    if (src == SRC_MEANT) DFA_BN_BWD(bf16_t, SRC_MEANT); else DFA_BN_BWD(bf16_t, SRC_POOL);
+  } else {
+    if (src == SRC_MEANT) DFA_BN_BWD(float, SRC_MEANT); else DFA_BN_BWD(float, SRC_POOL);
+  }
+#undef DFA_BN_BWD
+  return hipGetLastError();
+}
+
+hipError_t launch_bce_smooth(const float* logits, const float* labels, float eps, int B, float* loss, float* dlogits,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(bce_smooth_kernel, dim3(1), dim3(256), 0, s, logits, labels, eps, B, loss, dlogits);
+  return hipGetLastError();
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                        float wd, int step, float grad_scale, hipStream_t s) {
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  const float sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd,
+                     bc1, sqrt_bc2, grad_scale);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

@@ -62,6 +62,9 @@ int dfa_version(void);
 int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out);
 int dfa_ctx_destroy(dfa_ctx* ctx);
 int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
+/* tuning switches; "conv_dma" = 1 stages the MFMA convolutions' input rows with LDS-DMA (global_load_lds) instead of
+ * through registers (also settable with the environment variable DFA_CONV_DMA=1 before dfa_ctx_create) */
+int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value);
 const char* dfa_last_error(const dfa_ctx* ctx);
 const char* dfa_error_name(int code);
 
@@ -87,6 +90,32 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision);
 int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
                       int64_t stride_t, int64_t stride_f, float* logits, float* embedding,
                       void* workspace, size_t workspace_bytes);
+
+/* ---- CNN2D training step (replaces, for src/train.py:71-76, torch autograd over src/model.py:13-39) ------------ */
+size_t dfa_cnn2d_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F, int precision);
+/* train-mode forward: BatchNorm uses batch statistics (and updates running_mean/var in place through the pointers
+ * given to dfa_cnn2d_set_params when update_running_stats != 0, momentum 0.1 in the reference); Dropout(p_drop) after
+ * pools 1 and 2 with a Philox mask keyed by (seed, offset).  Uses the raw parameters directly (no prepare needed).
+ * The workspace keeps what dfa_cnn2d_backward needs; it must stay untouched until then. */
+int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                            int64_t stride_t, int64_t stride_f, int precision, float p_drop, uint64_t seed,
+                            uint64_t offset, float momentum, int update_running_stats, float* logits,
+                            float* embedding, void* workspace, size_t workspace_bytes);
+/* gradients of the 14 parameters w.r.t. sum_b dlogits[b]*logit[b], written (not accumulated) to grads[0..13] in
+ * parameters() order: conv.0.{weight,bias}, conv.1.{weight,bias}, conv.5.*, conv.6.*, conv.10.*, conv.11.*,
+ * classifier.{weight,bias}.  Pointing grads[] into ONE flat buffer gives the single all-reduce payload of data-parallel
+ * training (464,644 bytes). */
+int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                       int64_t stride_t, int64_t stride_f, const float* dlogits, float* const* grads, int ngrads,
+                       void* workspace, size_t workspace_bytes);
+/* loss = mean(BCEWithLogits(logits, y*(1-eps)+eps/2)), dlogits = dloss/dlogits   (src/train.py:311-320); device ptrs;
+ * loss and dlogits may be NULL. */
+int dfa_bce_smooth_fwd_bwd(dfa_ctx* ctx, const float* logits, const float* labels, float label_smoothing, int B,
+                           float* loss, float* dlogits);
+/* one torch.optim.AdamW step over a flat fp32 buffer: p *= 1-lr*wd; m,v update; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).
+ * grad_scale multiplies the gradient first (1/world after a sum all-reduce).  step is 1-based. */
+int dfa_adamw_step(dfa_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
 
 /* ---- CNN1D (replaces CNN1D.forward, src/model_cnn1d.py:37-46) -------------------------------------- */
 /* params: 20 device pointers (fp32) in state_dict order without num_batches_tracked:

@@ -161,3 +161,22 @@ def test_predict_end_to_end_eer_parity(tmp_path, golden):
         want = O.calculate_eer(ref_scores.tolist(), labels.tolist())
         assert res["eer"] == want[0], (res, want)
         assert 0.0 < res["eer"] < 1.0          # non-degenerate: the metric is sensitive to rank changes
+
+
+def test_cnn2d_lds_dma_staging_matches_register_staging(golden):
+    """The LDS-DMA (global_load_lds) input staging must give bit-identical results to register staging."""
+    from dfa_amd import _lib
+    sd, g = golden("cnn2d_eval")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    try:
+        for prec in ("fp32", "bf16"):
+            model = _model_from_sd(sd, precision=prec)
+            for tag in ("t321", "t7"):
+                x = torch.from_numpy(g[f"{tag}.x_stored"]).to("cuda").transpose(1, 2)
+                ctx.set_option("conv_dma", 0)
+                ref_l, ref_e = model(x, return_embedding=True)
+                ctx.set_option("conv_dma", 1)
+                dma_l, dma_e = model(x, return_embedding=True)
+                assert torch.equal(ref_e, dma_e) and torch.equal(ref_l, dma_l), (prec, tag)
+    finally:
+        ctx.set_option("conv_dma", 0)

@@ -1,0 +1,111 @@
+"""GPU parity tests of the CNN2D training step against the reference's own autograd/AdamW results
+(tests/golden/cnn2d_train.npz: dropout = 0, batch 4 x T 16, label smoothing 0 and 0.05)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh_model(g, precision="fp32"):
+    from dfa_amd.model import CNN2D
+    m = CNN2D(in_features=180, dropout=0.0, precision=precision)
+    sd = {k[len("init.sd."):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("init.sd.")}
+    m.load_state_dict(sd)
+    return m.to("cuda").train()
+
+
+NOISE_KEYS = ("conv.0.bias", "conv.5.bias", "conv.10.bias")
+
+
+def _check_state(sd, g, prefix, steps, atol, rtol):
+    """Compare a state_dict with the reference's.  Conv biases in front of a batch-stat BatchNorm have an exactly-zero
+    gradient; Adam normalises their rounding noise to +-lr per step, so their trajectory is noise in the reference too:
+    for them only the bound |delta| <= steps * lr is checked."""
+    for k, v in sd.items():
+        want = g[f"{prefix}.{k}"]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(want), k
+        elif k in NOISE_KEYS:
+            init = g["init.sd." + k]
+            assert np.abs(v.cpu().numpy() - init).max() <= steps * 1e-3 * 1.02 + 1e-6, k
+            assert np.abs(want - init).max() <= steps * 1e-3 * 1.02 + 1e-6, k
+        elif k.endswith("running_mean"):
+            # running_mean = momentum-average of mean(conv(x)) + conv bias: it inherits the bias noise above
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=atol + steps * 1e-3, rtol=rtol, err_msg=k)
+        else:
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=atol, rtol=rtol, err_msg=k)
+
+
+def _smooth(y, eps):
+    return y * (1.0 - eps) + 0.5 * eps if eps > 0 else y
+
+
+@pytest.mark.parametrize("tag,eps", [("ls0", 0.0), ("ls05", 0.05)])
+def test_train_step_autograd_path_matches_reference(golden, tag, eps):
+    _, g = golden("cnn2d_train")
+    model = _fresh_model(g)
+    x = torch.from_numpy(g[f"{tag}.x"]).to("cuda").transpose(1, 2)
+    y = torch.from_numpy(g[f"{tag}.y"]).to("cuda")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)     # src/train.py:326-328
+    logits = model(x).squeeze(-1)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, _smooth(y, eps))
+    opt.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[f"{tag}.logits"], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}.loss"], rtol=1e-5)
+    for name, p in model.named_parameters():
+        want = g[f"{tag}.grad.{name}"]
+        got = p.grad.cpu().numpy()
+        if name in ("conv.0.bias", "conv.5.bias", "conv.10.bias"):
+            # a bias in front of a batch-statistics BatchNorm has an exactly-zero gradient: both sides are fp32
+            # rounding noise; check it stays at the noise floor of the layer's weight gradient
+            floor = 1e-4 * np.abs(g[f"{tag}.grad.{name.replace('bias', 'weight')}"]).max() + 1e-6
+            assert np.abs(got).max() < floor and np.abs(want).max() < floor, name
+            continue
+        scale = max(np.abs(want).max(), 1e-6)
+        np.testing.assert_allclose(got, want, atol=2e-4 * scale + 1e-7, rtol=2e-3, err_msg=name)
+    opt.step()
+    _check_state(model.state_dict(), g, f"{tag}.after1", 1, atol=2e-5, rtol=2e-4)
+
+
+def test_native_trainer_three_steps_match_reference(golden):
+    from dfa_amd.training.train_step import NativeTrainer
+    _, g = golden("cnn2d_train")
+    model = _fresh_model(g)
+    tr = NativeTrainer(model, lr=1e-3, weight_decay=0.01, label_smoothing=0.05)
+    for step, (kx, ky) in enumerate((("ls05.x", "ls05.y"), ("ls05.x2", "ls05.y2"), ("ls05.x3", "ls05.y3")), 1):
+        x = torch.from_numpy(g[kx]).to("cuda").transpose(1, 2)
+        loss = tr.step(x, torch.from_numpy(g[ky]))
+        if step == 1:
+            np.testing.assert_allclose(loss.item(), g["ls05.loss"], rtol=1e-5)
+    _check_state(model.state_dict(), g, "ls05.after3", 3, atol=1e-4, rtol=2e-3)
+    # parameters are views of one flat buffer: the data-parallel payload is a single tensor
+    assert tr.flat_g.numel() == 116_161 and all(p.data_ptr() >= tr.flat_p.data_ptr() for p in model.parameters())
+    # the eval path re-folds the updated weights
+    model.eval()
+    assert torch.isfinite(model(torch.from_numpy(g["ls05.x"]).to("cuda").transpose(1, 2))).all()
+
+
+def test_train_bf16_mode_and_dropout_run(golden):
+    """bf16 storage mode and dropout > 0: gradients stay close to the fp32 ones / finite and mask-consistent."""
+    _, g = golden("cnn2d_train")
+    x = torch.from_numpy(g["ls0.x"]).to("cuda").transpose(1, 2)
+    y = torch.from_numpy(g["ls0.y"]).to("cuda")
+    model = _fresh_model(g, precision="bf16")
+    loss = torch.nn.BCEWithLogitsLoss()(model(x).squeeze(-1), y)
+    loss.backward()
+    for name, p in model.named_parameters():
+        if name in NOISE_KEYS:
+            continue
+        want = g[f"ls0.grad.{name}"]
+        rel = np.abs(p.grad.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-6)
+        assert rel < 0.25, (name, rel)      # bf16 storage of z/dz on a 4 x 16-frame batch: coarse agreement only
+    model = _fresh_model(g)
+    model.dropout = 0.3
+    torch.manual_seed(0)
+    l1 = model(x)
+    l1.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    l2 = model(x)                                       # a new mask every call
+    assert not torch.equal(l1, l2)
