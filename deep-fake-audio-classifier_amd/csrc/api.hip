@@ -115,8 +115,8 @@ int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out) {
     delete c;
     return DFA_E_HIP;
   }
-  const char* dma = getenv("DFA_CONV_DMA");
-  c->conv_dma = (dma && dma[0] == '1') ? 1 : 0;
+  const char* dma = getenv("DFA_CONV_DMA");   // unset = per-kernel choice measured on MI355X (see launch_cnn2d_block*)
+  c->conv_dma = (dma && (dma[0] == '0' || dma[0] == '1')) ? dma[0] - '0' : -1;
   *out = c;
   return DFA_OK;
 }
@@ -147,7 +147,7 @@ const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null c
 
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return DFA_E_NULL_PTR;
-  if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value < 0 ? -1 : (value ? 1 : 0); return DFA_OK; }
   return fail(ctx, DFA_E_UNSUPPORTED, "unknown option '%s'", name);
 }
 
@@ -223,7 +223,7 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   m.c3.wpack = (uint4*)(wp + w2_bytes);
   const float* const* p = m.p;
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, ctx->stream));
-  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 0, 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 0, 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream, 1, 0.5f));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 0, 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
   m.prepared_prec = precision;
   return DFA_OK;
@@ -386,16 +386,16 @@ int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, s));
   for (int l = 0; l < 2; ++l) {
     const float* const* q = p + 6 * (l + 1);
-    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], ecin[l], 0, ecin[l], ecout[l], precision, m.enc[l].wpack, m.enc[l].bias, s));
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], ecin[l], 0, ecin[l], ecout[l], precision, m.enc[l].wpack, m.enc[l].bias, s, 1, 0.25f));
   }
   {
     const float* const* q = p + 18;
     if (precision == DFA_PREC_BF16) {
-      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 0, 128, 256, precision, m.enc[2].wpack, m.enc[2].bias, s));
+      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 0, 128, 256, precision, m.enc[2].wpack, m.enc[2].bias, s, 1, 0.25f));
     } else {  // two Cin halves, see conv3x3_inst_cae.hip
-      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 0, 64, 256, precision, m.enc[2].wpack, m.enc[2].bias, s));
+      DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 0, 64, 256, precision, m.enc[2].wpack, m.enc[2].bias, s, 1, 0.25f));
       DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(q[0], q[1], q[2], q[3], q[4], q[5], 128, 64, 64, 256, precision,
-                                                  m.enc[2].wpack + (size_t)(256 / 32) * 9 * 8 * 64, m.enc[2].bias, s));
+                                                  m.enc[2].wpack + (size_t)(256 / 32) * 9 * 8 * 64, m.enc[2].bias, s, 1, 0.25f));
     }
   }
   for (int l = 0; l < 3; ++l) {

@@ -15,6 +15,8 @@ constexpr int C1_TF = 16;  // feature columns per tile
 constexpr int C1_XR = 2 * C1_TI + 2;
 constexpr int C1_XC = C1_TF + 2;
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <typename TX>
 __device__ __forceinline__ float load_x(const TX* p);
 template <>
@@ -22,63 +24,111 @@ __device__ __forceinline__ float load_x<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float load_x<bf16_t>(const bf16_t* p) { return bf16_to_float(*p); }
 
+// Thread = (pooled pixel, channel octet): lanes 4p..4p+3 own the four 8-channel groups of pixel p, so one wave store
+// instruction writes 16 pixels x 64 bytes = 1 KiB of contiguous channels-last output.  The thread keeps its 8 x 9
+// folded weights in registers (as 4 channel pairs x 9 taps) and walks 4 pixels of the 16 x 16 tile; every tap of every
+// pre-pool row is one packed v_pk_fma_f32 on a channel pair.
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __restrict__ x, int64_t sb, int64_t st,
                                                                    int64_t sf, const float* __restrict__ w1,
                                                                    const float* __restrict__ b1, TO* __restrict__ out,
                                                                    int T, int F, int Ho, DropCfg dc) {
-  __shared__ float xs[C1_XR][C1_XC + 1];
+  __shared__ float xs[2][C1_XR][C1_XC + 1];
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
-  const int i0 = blockIdx.y * C1_TI, f0 = blockIdx.x * C1_TF;
+  const int f0 = blockIdx.x * C1_TF;
   const TX* xb = x + (int64_t)b * sb;
-  const int t_base = 2 * i0 - 1, f_base = f0 - 1;
-  // stage the x tile; walk the contiguous axis with consecutive threads
+  const int f_base = f0 - 1;
   const bool t_fast = (st == 1);
-  for (int e = tid; e < C1_XR * C1_XC; e += 256) {
-    int rr, cc;
-    if (t_fast) { cc = e / C1_XR; rr = e - cc * C1_XR; } else { rr = e / C1_XC; cc = e - rr * C1_XC; }
-    const int t = t_base + rr, f = f_base + cc;
-    float v = 0.f;
-    if (t >= 0 && t < T && f >= 0 && f < F) v = load_x<TX>(xb + (int64_t)t * st + (int64_t)f * sf);
-    xs[rr][cc] = v;
+  constexpr int NX = (C1_XR * C1_XC + 255) / 256;   // x elements per thread per tile
+  // x tile of the row tile starting at pooled row i0 -> registers (walk the contiguous axis with consecutive threads)
+  auto load_tile = [&](int i0, float* xr) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = k * 256 + tid;
+      int rr, cc;
+      if (t_fast) { cc = e / C1_XR; rr = e - cc * C1_XR; } else { rr = e / C1_XC; cc = e - rr * C1_XC; }
+      const int t = 2 * i0 - 1 + rr, f = f_base + cc;
+      float v = 0.f;
+      if (e < C1_XR * C1_XC && t >= 0 && t < T && f >= 0 && f < F) v = load_x<TX>(xb + (int64_t)t * st + (int64_t)f * sf);
+      xr[k] = v;
+    }
+  };
+  auto store_tile = [&](int buf, const float* xr) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int e = k * 256 + tid;
+      int rr, cc;
+      if (t_fast) { cc = e / C1_XR; rr = e - cc * C1_XR; } else { rr = e / C1_XC; cc = e - rr * C1_XC; }
+      if (e < C1_XR * C1_XC) xs[buf][rr][cc] = xr[k];
+    }
+  };
+  const int q = tid & 3, pl = tid >> 2;   // channel octet, pixel lane (0..63)
+  f32x2_t wv[4][9], bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[c][k] = (f32x2_t){w1[(q * 8 + 2 * c) * 9 + k], w1[(q * 8 + 2 * c + 1) * 9 + k]};
+    bv[c] = (f32x2_t){b1[q * 8 + 2 * c], b1[q * 8 + 2 * c + 1]};
+  }
+  const int fi = pl & (C1_TF - 1), rq = pl >> 4;   // 16 columns x 4 rows per pass
+  const int f = f0 + fi;
+  // the block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ...; the next tile's x is fetched (global -> VGPR)
+  // while the current one is computed, and lands in the other LDS buffer before the single barrier of the iteration
+  const int ntiles = (Ho + C1_TI - 1) / C1_TI;
+  float xr[NX];
+  int buf = 0;
+  if ((int)blockIdx.y < ntiles) {
+    load_tile(blockIdx.y * C1_TI, xr);
+    store_tile(0, xr);
   }
   __syncthreads();
-  const int fi = tid & (C1_TF - 1), ri = tid / C1_TF;
-  const int i = i0 + ri, f = f0 + fi;
-  if (i >= Ho || f >= F) return;
-  float xv[4][3];
+  for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+    const int i0 = tile * C1_TI;
+    const bool more = tile + (int)gridDim.y < ntiles;
+    if (more) load_tile((tile + gridDim.y) * C1_TI, xr);
+#pragma unroll 1
+    for (int pass = 0; pass < C1_TI / 4; ++pass) {
+      const int ri = pass * 4 + rq;
+      const int i = i0 + ri;
+      if (i >= Ho || f >= F) continue;
+      f32x2_t xp[4][3];   // x rows 2i-1 .. 2i+2, broadcast to both halves of the channel pair
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int d = 0; d < 3; ++d) xv[a][d] = xs[2 * ri + a][fi + d];
-
-  TO* op = out + (((size_t)b * Ho + i) * F + f) * 32;
-  constexpr int VEC = 16 / (int)sizeof(TO);  // output channels per 16-byte store
-  float ds[32];                                // train mode: dropout keep-scale of this pixel's 32 channels
-  if (dc.thresh != 0) {
+        for (int d = 0; d < 3; ++d) { const float xv = xs[buf][2 * ri + a][fi + d]; xp[a][d] = (f32x2_t){xv, xv}; }
+      const uint64_t oidx = (((uint64_t)b * Ho + i) * F + f) * 32 + q * 8;
+      float o[8];
 #pragma unroll
-    for (int c0 = 0; c0 < 32; c0 += 8) drop_scale8(dc, (((uint64_t)b * Ho + i) * F + f) * 32 + c0, ds + c0);
-  }
+      for (int c = 0; c < 4; ++c) {
+        f32x2_t a0 = bv[c], a1 = bv[c];   // pre-pool rows 2i and 2i+1
 #pragma unroll
-  for (int c0 = 0; c0 < 32; c0 += VEC) {
-    TO ov[VEC];
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-      const float* wc = w1 + (c0 + c) * 9;  // uniform address -> scalar loads
-      float v0 = b1[c0 + c], v1 = v0;
+          for (int d = 0; d < 3; ++d) {
+            a0 = __builtin_elementwise_fma(wv[c][dy * 3 + d], xp[dy][d], a0);
+            a1 = __builtin_elementwise_fma(wv[c][dy * 3 + d], xp[dy + 1][d], a1);
+          }
+        o[2 * c] = 0.5f * (fmaxf(a0.x, 0.f) + fmaxf(a1.x, 0.f));
+        o[2 * c + 1] = 0.5f * (fmaxf(a0.y, 0.f) + fmaxf(a1.y, 0.f));
+      }
+      if (dc.thresh != 0) {
+        float ds[8];
+        drop_scale8(dc, oidx, ds);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+        for (int c = 0; c < 8; ++c) o[c] *= ds[c];
+      }
+      TO ov[8];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          v0 = fmaf(wc[dy * 3 + d], xv[dy][d], v0);
-          v1 = fmaf(wc[dy * 3 + d], xv[dy + 1][d], v1);
-        }
-      float o = 0.5f * (fmaxf(v0, 0.f) + fmaxf(v1, 0.f));
-      if (dc.thresh != 0) o *= ds[c0 + c];
-      ov[c] = cvt_out<TO>(o);
+      for (int c = 0; c < 8; ++c) ov[c] = cvt_out<TO>(o[c]);
+      TO* op = out + oidx;
+#pragma unroll
+      for (int v = 0; v < (int)(8 * sizeof(TO) / 16); ++v)
+        reinterpret_cast<uint4*>(op)[v] = reinterpret_cast<const uint4*>(ov)[v];
     }
-    *reinterpret_cast<uint4*>(op + c0) = *reinterpret_cast<const uint4*>(ov);
+    if (more) store_tile(buf ^ 1, xr);
+    __syncthreads();
+    buf ^= 1;
   }
 }
 
@@ -88,7 +138,11 @@ hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int6
   DropCfg dc{};
   if (drop) dc = *drop;
   const int Ho = T / 2;
-  dim3 grid((F + C1_TF - 1) / C1_TF, (Ho + C1_TI - 1) / C1_TI, B), block(256);
+  // few row-tile walkers per (utterance, column tile) once the batch alone fills the chip; more for small batches
+  const int ntiles = (Ho + C1_TI - 1) / C1_TI, ncols = (F + C1_TF - 1) / C1_TF;
+  int ny = (4096 + B * ncols - 1) / (B * ncols);
+  ny = ny < 1 ? 1 : (ny > ntiles ? ntiles : ny);
+  dim3 grid(ncols, ny, B), block(256);
   if (x_dtype == DFA_DTYPE_F32 && out_prec == DFA_PREC_F32)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, float>), grid, block, 0, s, (const float*)x, sb, st, sf, w1,
                        b1, (float*)out, T, F, Ho, dc);

@@ -3,36 +3,49 @@
 //
 // Replaces, per launch, one "Conv2d -> BatchNorm2d -> ReLU [-> AvgPool2d]" group of the reference:
 //   src/model.py:21-25 (block 2), :27-29 + :37 (block 3 + mean over T),
-//   src/model_cae.py:40-55 (encoder blocks 2-4).
+//   src/model_cae.py:40-55 (encoder blocks 2-4); in train mode (EPI_PLAIN) it stores the pre-BatchNorm output
+//   and serves as the data-gradient convolution of loss.backward() (src/train.py:75).
 //
 // Data layout (HBM): activations are channels-last  act[b][t][f][c]  so that one tap of one pixel is
 // CIN contiguous elements; weights are pre-packed by pack.hip in the exact register order the MFMA
-// B-operand wants:  wpack[cout/32][tap][kgroup][lane] (16 bytes each).
+// operand wants:  wpack[cout/32][tap][kgroup][lane] (16 bytes each).
 //
 // Work decomposition
-//   workgroup  = (utterance b, strip of 32*MT feature columns, chunk of 32*NSL output channels); it walks
+//   workgroup  = (utterance b, strip of 32 feature columns, chunk of 32*NSL output channels); it walks
 //                DOWN the time axis keeping a ring of input rows in LDS, so every input element is read from
 //                HBM once per strip (+2 halo columns) and there is no vertical halo re-read.
 //   wave       = (N-slice nsl of 32 output channels, M-group mg).  The wave keeps its full 9 x CIN x 32 weight
-//                slice in VGPRs for the whole kernel (B operand), and streams A fragments from the LDS ring.
-//   iteration  = 2*RP output rows (RP row pairs).  A "unit" is one pair of 32-pixel M tiles (rows t, t+1; same
-//                32 columns): both accumulators share the A fragments of the two input rows they have in
+//                slice in VGPRs for the whole kernel, and streams activation fragments from the LDS ring.
+//   iteration  = 2*RP output rows (RP row pairs).  A "unit" is one pair of 32-pixel tiles (rows t, t+1; same
+//                32 columns): both accumulators share the fragments of the two input rows they have in
 //                common, so a unit issues 12*NKG ds_read_b128 for 18*NKG k-groups of MFMA work.
-//   staging    = block j of the ring holds input rows [2RP*j-1, 2RP*(j+1)-1).  Iteration `it` computes from
-//                blocks it, it+1 while block it+2 is fetched (global -> VGPR before the MFMAs, VGPR -> LDS after
-//                them), one __syncthreads() per iteration.
+//   staging    = ring block j holds input rows [2RP*j-1, 2RP*(j+1)-1).  Iteration `it` computes from
+//                blocks it, it+1 while block it+2 is fetched (through registers, or by LDS-DMA), one
+//                __syncthreads() per iteration.
 //
-// LDS image: pixel p (linear index ring_row*SLOTS + slot) owns PB = CIN*sizeof(T) bytes = CPP 16-byte chunks;
-// chunk c is stored at physical chunk  c ^ swz(p)  so that the 16 lanes of every ds_read_b128 lane group
-// (consecutive pixels, same logical chunk) hit 16 different 16-byte bank slots (MI355X_MICROARCH "LDS").
+// Instruction economy (rocprofv3 showed ~5 VALU per MFMA in the first version; the matrix pipe shares issue slots
+// with the VALU):
+//   * LDS image: pixel slot s of ring row q owns PB = CIN*sizeof(T) bytes at (q*SP + s)*PB; 16-byte chunk c sits at
+//     physical chunk c ^ swz(s).  The swizzle depends on the COLUMN only and SP*PB is a multiple of 256 bytes, so
+//     (a) the 16 lanes of every ds_read_b128 lane group (consecutive columns, same logical chunk) hit 16 distinct
+//     bank slots, and (b) a lane's byte offset inside a row is loop-invariant: it is computed once, the k-group is
+//     one XOR with an immediate, and -- the iteration loop being unrolled over the ring period 3 -- the row offset
+//     is an instruction immediate.
+//   * staging addresses are per-thread constants plus a per-iteration scalar.
+//   * MFMA operands are swapped: weights are the A operand, activations the B operand, so the accumulator holds
+//     pixel = lane&31 and channels (i&3)+8*(i>>2)+4*(lane>>5) in its 16 registers.  Bias is the accumulator's initial
+//     value; every lane owns 4 consecutive channels x 4 groups of its pixel, which become 16-byte stores (bf16: after
+//     one v_permlane32_swap per dword, the T21 idiom of the CDNA guide); the time-mean epilogue writes whole rows of
+//     the embedding with no transpose.
+//   * average pooling's 1/2 (1/4) is folded into the packed weights and bias (relu(s*x) = s*relu(x), s > 0, exact).
 //
-// MFMA: bf16 -> v_mfma_f32_32x32x16_bf16 (A: 8 bf16 per lane = one 16-byte chunk);
+// MFMA: bf16 -> v_mfma_f32_32x32x16_bf16 (8 bf16 per lane = one 16-byte chunk);
 //       f32  -> v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; one 16-byte chunk feeds 4 MFMAs).
-//       Lane (r = lane&31, h = lane>>5) reads logical chunk 2*kg+h of pixel r (+tap shift), i.e. input channels
-//       KG*kg + (KG/2)*h + j.  C/D: column (= output channel) lane&31, row (= pixel) (i&3)+8*(i>>2)+4*h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 namespace dfa {
 
@@ -49,6 +62,11 @@ __device__ __forceinline__ bf16_t float_to_bf16(float f) {
   bf16_t r;
   r.v = __builtin_bit_cast(unsigned short, b);
   return r;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
 template <typename T>
 __device__ __forceinline__ T cvt_out(float f);
@@ -73,69 +91,76 @@ struct ConvArgs {
   // CIN-channel window of wider pixels, start from previously stored partial sums and/or store raw partial sums.
   int in_pix_bytes;    // bytes between consecutive input pixels (0 = CIN*sizeof(T), i.e. dense)
   int in_ch_off_bytes; // byte offset of this launch's first input channel inside a pixel
-  const float* acc_in; // ACCIN: [B][H][W][COUT] fp32 partial sums to start from
-  float* raw_out;      // EPI_RAW: [B][H][W][COUT] fp32 partial sums (no bias, no activation)
+  const float* acc_in; // ACCIN: [B][H][W][COUT] fp32 partial sums to start from (they already contain the bias)
+  float* raw_out;      // EPI_RAW: [B][H][W][COUT] fp32 partial sums (bias included, no activation)
   // train-mode BatchNorm statistics (EPI_PLAIN only): per-workgroup partial sums of the stored values v and v*v
   // per output channel, partial[(blockIdx.x * COUT + channel) * 2 + {0,1}]; reduced in a fixed order by bn_finalize.
   float* stats_partial;
   const void* zero_page;  // DMA staging: >= 16 zero bytes in device memory (source of out-of-image chunks)
 };
 
+// chunk swizzle as a function of the pixel slot (column) only
 template <int PB>
-__device__ __forceinline__ int lds_swz(int p) {
-  if (PB == 64) return (p >> 2) & 3;
-  if (PB == 128) return (p >> 1) & 7;
-  return p & 15;  // 256, 512
+__device__ __forceinline__ int lds_swz(int slot) {
+  if (PB == 64) return (slot >> 2) & 3;
+  if (PB == 128) return (slot >> 1) & 7;
+  return slot & 15;  // 256, 512, 1024
 }
 
+// acc += W(A operand: 32 channels x K) . X(B operand: K x 32 pixels)
 template <typename T>
 struct Mma;
 template <>
 struct Mma<bf16_t> {
-  static __device__ __forceinline__ f32x16_t run(const uint4& a, const uint4& b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+  static __device__ __forceinline__ f32x16_t run(const uint4& w, const uint4& x, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c,
                                                    0, 0, 0);
   }
 };
 template <>
 struct Mma<float> {
-  static __device__ __forceinline__ f32x16_t run(const uint4& a, const uint4& b, f32x16_t c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  static __device__ __forceinline__ f32x16_t run(const uint4& w, const uint4& x, f32x16_t c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), c, 0, 0, 0);
     return c;
   }
 };
 
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI>
+template <typename T, int CIN, int NSL, int MG, int RP, int EPI>
 struct ConvCfg {
   static constexpr int ES = sizeof(T);
   static constexpr int KG = 32 / ES;       // input channels per k-group (two 16-byte chunks)
   static constexpr int NKG = CIN / KG;
   static constexpr int PB = CIN * ES;      // bytes per pixel
   static constexpr int CPP = PB / 16;      // 16-byte chunks per pixel
-  static constexpr int SLOTS = 32 * MT + 2;
+  static constexpr int SLOTS = 34;         // 32 columns + 2 halo
+  static constexpr int SPA = (PB >= 256) ? 1 : 256 / PB;          // row pitch must make SP*PB a multiple of 256 B
+  static constexpr int SP = (SLOTS + SPA - 1) / SPA * SPA;
   static constexpr int BR = 2 * RP;        // rows per ring block
   static constexpr int NT = 64 * NSL * MG;
-  static constexpr int NCH = BR * SLOTS * CPP;
+  static constexpr int NCH = BR * SP * CPP;  // physical chunks per ring block
   static constexpr int NLD = (NCH + NT - 1) / NT;
-  static constexpr int UNITS = RP * MT;
-  static constexpr int UPW = UNITS / MG;   // units per wave per iteration
-  static constexpr int RING_BYTES = 3 * BR * SLOTS * PB;
-  static constexpr int EPI_LDW = 32 * MT + 1;
-  static constexpr int EPI_BYTES = (EPI == EPI_MEAN_T) ? NSL * 32 * EPI_LDW * 4 : 0;
-  static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-  static_assert(UNITS % MG == 0, "units must split evenly over the M groups");
+  static constexpr int UPW = RP / MG;      // units per wave per iteration
+  static constexpr int ROW_BYTES = SP * PB;
+  static constexpr int RING_BYTES = 3 * BR * ROW_BYTES;
+  static constexpr int BIAS_BYTES = NSL * 32 * 4;
+  static constexpr int STAT_BYTES = (EPI == EPI_PLAIN) ? MG * NSL * 32 * 2 * 4 : 0;
+  static constexpr int LDS_BYTES = RING_BYTES + BIAS_BYTES + STAT_BYTES;
+  static_assert(RP % MG == 0, "row pairs must split evenly over the M groups");
   static_assert((BR & (BR - 1)) == 0, "rows per block must be a power of two");
   static_assert(EPI != EPI_MEAN_T || MG == 1, "time-mean epilogue keeps column sums per wave: MG must be 1");
   static_assert(CIN % KG == 0, "CIN must be a multiple of the k-group");
 };
 
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false>
+template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false,
+          bool STATS = false>
 __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvArgs a) {
-  using C = ConvCfg<T, CIN, NSL, MG, RP, MT, EPI>;
-  constexpr int PB = C::PB, CPP = C::CPP, SLOTS = C::SLOTS, BR = C::BR, NT = C::NT, NKG = C::NKG;
+  static_assert(MT == 1, "strips are 32 columns wide");
+  using C = ConvCfg<T, CIN, NSL, MG, RP, EPI>;
+  constexpr int PB = C::PB, CPP = C::CPP, SP = C::SP, BR = C::BR, NT = C::NT, NKG = C::NKG, ROWB = C::ROW_BYTES;
+  static_assert(!STATS || EPI == EPI_PLAIN, "BatchNorm statistics ride on the PLAIN epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -152,15 +177,15 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int b = logical / a.nstrips;
   const int strip = logical - b * a.nstrips;
-  const int f0 = strip * (32 * MT);
+  const int f0 = strip * 32;
   const int H = a.H, W = a.W, COUT = a.COUT;
   const int cout_base = blockIdx.y * (NSL * 32);
-  const int n = cout_base + nsl * 32 + r;  // this lane's output channel
+  const int nb = cout_base + nsl * 32;  // first output channel of this wave's slice
 
   const int ipb = a.in_pix_bytes ? a.in_pix_bytes : PB;
   const char* in_b = (const char*)a.in + (size_t)b * H * W * ipb + a.in_ch_off_bytes;
 
-  // ---- weights: the wave's [9][NKG] 16-byte B fragments stay in registers for the whole kernel
+  // ---- weights: the wave's [9][NKG] 16-byte fragments stay in registers for the whole kernel
   uint4 w[9][NKG];
   {
     const uint4* wp = a.wpack + ((size_t)(blockIdx.y * NSL + nsl) * 9 * NKG) * 64 + lane;
@@ -169,72 +194,79 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
 #pragma unroll
       for (int kg = 0; kg < NKG; ++kg) w[tap][kg] = wp[(tap * NKG + kg) * 64];
   }
-  const float bv = a.bias[n];
+  float* bias_lds = (float*)(smem + C::RING_BYTES);
+  if (tid < NSL * 32) bias_lds[tid] = a.bias[cout_base + tid];
 
-  // ---- staging of ring block j: input rows t = BR*j - 1 + rowi, slots f = f0 - 1 + slot
-  uint4 stg[C::NLD];
-  auto stage_load = [&](int j) {
+  // ---- per-lane fragment offsets inside a ring row (loop-invariant): slot = r + dx, logical chunk 2*kg + h.
+  // xa[dx] carries the kg = 0 address; k-group kg is xa[dx] ^ (kg << 5) (see header).
+  int xa[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int slot = r + dx, s = lds_swz<PB>(slot);
+    xa[dx] = slot * PB + (((h ^ (s & 1)) << 4) | ((s >> 1) << 5));
+  }
+
+  // ---- staging constants: thread's k-th PHYSICAL chunk of a ring block (pad slots and out-of-image columns -> zeros)
+  int s_off[C::NLD];     // source byte offset relative to row (BR*j - 1), -1 when the column is never valid
+#pragma unroll
+  for (int k = 0; k < C::NLD; ++k) {
+    const int g = k * NT + tid;
+    const int rowi = g / (SP * CPP), rem = g - rowi * (SP * CPP);
+    const int slot = rem / CPP, cph = rem % CPP;
+    const int c = cph ^ lds_swz<PB>(slot);
+    const int f = f0 - 1 + slot;
+    const bool ok = (g < C::NCH) && (slot < C::SLOTS) && (f >= 0) && (f < W);
+    s_off[k] = ok ? (rowi * W + f) * ipb + c * 16 : -1;
+  }
+  uint4 stg[DMA ? 1 : C::NLD];
+  auto stage_load = [&](int j) {  // global -> registers
 #pragma unroll
     for (int k = 0; k < C::NLD; ++k) {
-      const int g = k * NT + tid;
+      const int t = BR * j - 1 + (k * NT + tid) / (SP * CPP);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (g < C::NCH) {
-        const int rowi = g / (SLOTS * CPP);
-        const int rem = g - rowi * (SLOTS * CPP);
-        const int slot = rem / CPP, c = rem % CPP;
-        const int t = BR * j - 1 + rowi, f = f0 - 1 + slot;
-        if (t >= 0 && t < H && f >= 0 && f < W) v = *(const uint4*)(in_b + ((size_t)t * W + f) * ipb + c * 16);
-      }
-      stg[k] = v;
+      if (s_off[k] >= 0 && t >= 0 && t < H) v = *(const uint4*)(in_b + (ptrdiff_t)(BR * j - 1) * W * ipb + s_off[k]);
+      stg[DMA ? 0 : k] = v;
     }
   };
-  auto stage_store = [&](int ringblk) {
+  auto stage_store = [&](int ringblk) {  // registers -> LDS (physical chunk order)
 #pragma unroll
     for (int k = 0; k < C::NLD; ++k) {
       const int g = k * NT + tid;
-      if (g < C::NCH) {
-        const int rowi = g / (SLOTS * CPP);
-        const int rem = g - rowi * (SLOTS * CPP);
-        const int slot = rem / CPP, c = rem % CPP;
-        const int p = (ringblk * BR + rowi) * SLOTS + slot;
-        *(uint4*)(smem + p * PB + ((c ^ lds_swz<PB>(p)) << 4)) = stg[k];
-      }
+      if (g < C::NCH) *(uint4*)(smem + ringblk * BR * ROWB + g * 16) = stg[DMA ? 0 : k];
     }
   };
-
   // LDS-DMA variant (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  One wave instruction fills 64
-  // consecutive PHYSICAL 16-byte chunks (1 KiB, wave-uniform LDS base + lane*16), so the chunk swizzle is applied to
-  // the per-lane SOURCE address: the lane that owns physical chunk c' of pixel p fetches logical chunk c' ^ swz(p).
-  // Out-of-image chunks read a 16-byte zero page.  The transfers are retired by the vmcnt(0) hipcc emits at the
-  // iteration's __syncthreads().
+  // consecutive PHYSICAL 16-byte chunks (wave-uniform LDS base + lane*16); the swizzle lives in the per-lane SOURCE
+  // address.  Out-of-image chunks read a 16-byte zero page.  Retired by the vmcnt(0) of the iteration's barrier.
   auto stage_dma = [&](int j, int ringblk) {
 #pragma unroll
     for (int k = 0; k < C::NLD; ++k) {
       const int g = k * NT + tid;
       if (g < C::NCH) {
-        const int pix = g / CPP, cph = g % CPP;
-        const int rowi = pix / SLOTS, slot = pix - rowi * SLOTS;
-        const int p = ringblk * BR * SLOTS + pix;
-        const int c = cph ^ lds_swz<PB>(p);
-        const int t = BR * j - 1 + rowi, f = f0 - 1 + slot;
-        const char* src = (t >= 0 && t < H && f >= 0 && f < W) ? in_b + ((size_t)t * W + f) * ipb + c * 16
-                                                               : (const char*)a.zero_page;
-        char* dst = smem + ((size_t)ringblk * BR * SLOTS * CPP + k * NT + wave * 64) * 16;
+        const int t = BR * j - 1 + g / (SP * CPP);
+        const char* src = (s_off[k] >= 0 && t >= 0 && t < H) ? in_b + (ptrdiff_t)(BR * j - 1) * W * ipb + s_off[k]
+                                                             : (const char*)a.zero_page;
+        char* dst = smem + ringblk * BR * ROWB + (k * NT + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     }
   };
 
-  float cs[EPI == EPI_MEAN_T ? MT : 1][16];
+  // ---- epilogue state
+  float cs[EPI == EPI_MEAN_T ? 16 : 1];              // MEAN_T: running column sums (pixel = lane, channel = register)
+  float st1[STATS ? 16 : 1], st2[STATS ? 16 : 1];    // PLAIN: per-channel sum / sum of squares over this lane's pixels
   if (EPI == EPI_MEAN_T) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) cs[m][i] = 0.f;
+    for (int i = 0; i < 16; ++i) cs[i] = 0.f;
   }
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
+  }
+  const int col = f0 + r;                    // this lane's output pixel column
+  const bool col_ok = col < W;
 
-  float st1 = 0.f, st2 = 0.f;  // EPI_PLAIN: running sum / sum of squares of this lane's channel
   const int niter = (H + BR - 1) / BR;
   if (DMA) {
     stage_dma(0, 0);
@@ -247,166 +279,228 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
   }
   __syncthreads();
 
-  int blk0 = 0;  // it % 3
-  for (int it = 0; it < niter; ++it) {
-    const bool pf = (it + 1 < niter);
-    const int blk1 = (blk0 == 2) ? 0 : blk0 + 1;
-    const int blk2 = (blk1 == 2) ? 0 : blk1 + 1;
-    if (pf) {
-      if (DMA) stage_dma(it + 2, blk2); else stage_load(it + 2);
+  // one unit: output rows t0 = BR*it + 2*RPI, t0+1; PH = it % 3 (ring phase), both compile-time
+  auto unit = [&](auto ph_c, auto rp_c, int it) {
+    constexpr int PH = decltype(ph_c)::value, RPI = decltype(rp_c)::value;
+    f32x16_t acc0, acc1;
+    const int t0 = BR * it + 2 * RPI;
+    if (ACCIN) {
+      const float* i0 = a.acc_in + (((size_t)b * H + t0) * W + col) * COUT + nb + 4 * h;
+      const float* i1 = i0 + (size_t)W * COUT;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (col_ok && t0 < H) v0 = *(const float4*)(i0 + 8 * g);
+        if (col_ok && t0 + 1 < H) v1 = *(const float4*)(i1 + 8 * g);
+        acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
+        acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
+      }
+    } else {  // bias is the accumulator's initial value (EPI_RAW partial sums carry it into the ACCIN launch)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *(const float4*)(bias_lds + nsl * 32 + 8 * g + 4 * h);
+        acc0[4 * g] = bv.x; acc0[4 * g + 1] = bv.y; acc0[4 * g + 2] = bv.z; acc0[4 * g + 3] = bv.w;
+        acc1[4 * g] = bv.x; acc1[4 * g + 1] = bv.y; acc1[4 * g + 2] = bv.z; acc1[4 * g + 3] = bv.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // input row key q = BR*it + 2*RPI + i  (input row t = q - 1)
+      const int ringrow = (BR * PH + 2 * RPI + i) % (3 * BR);   // compile-time after unrolling
+      const char* rowp = smem + ringrow * ROWB;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) {
+          const uint4 xv = *(const uint4*)(rowp + (xa[dx] ^ (kg << 5)));
+          if (i <= 2) acc0 = Mma<T>::run(w[i * 3 + dx][kg], xv, acc0);
+          if (i >= 1) acc1 = Mma<T>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
+        }
+      }
     }
 
+    // ---- fused epilogue.  Register i <-> channel nb + (i&3) + 8*(i>>2) + 4*h of pixel (row, col).
+    if (EPI == EPI_POOL_H2) {
+      const int Ho = H >> 1, to = t0 >> 1;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc0[i], 0.f) + fmaxf(acc1[i], 0.f);   // 1/2 is in the weights
+      T* o = (T*)a.out + (((size_t)b * Ho + to) * W + col) * COUT + nb;
+      const bool ok = (to < Ho) && col_ok;
+      if (sizeof(T) == 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (ok) *(float4*)((float*)o + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {  // groups (g, g+1): swap halves so each lane owns 8 consecutive channels
+          const unsigned a0 = pack_bf16x2(v[4 * g], v[4 * g + 1]), a1 = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
+          const unsigned b0 = pack_bf16x2(v[4 * g + 4], v[4 * g + 5]), b1 = pack_bf16x2(v[4 * g + 6], v[4 * g + 7]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          // lanes < 32: [own g | upper's g] = channels 8g..8g+7; lanes >= 32: [lower's g+1 | own g+1] = 8g+8..8g+15
+          if (ok) *(uint4*)((bf16_t*)o + 8 * g + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+    } else if (EPI == EPI_POOL_2X2) {
+      const int Ho = H >> 1, Wo = W >> 1, to = t0 >> 1;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float s = fmaxf(acc0[i], 0.f) + fmaxf(acc1[i], 0.f);      // 1/4 is in the weights
+        v[i] = s + __shfl_xor(s, 1, 64);                                  // + the neighbouring column (lane r ^ 1)
+      }
+      const int fo = col >> 1;
+      if (to < Ho && fo < Wo && (r & 1) == 0) {
+        T* o = (T*)a.out + (((size_t)b * Ho + to) * Wo + fo) * COUT + nb;
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(float4*)((float*)o + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(uint2*)((bf16_t*)o + 8 * g + 4 * h) =
+                make_uint2(pack_bf16x2(v[4 * g], v[4 * g + 1]), pack_bf16x2(v[4 * g + 2], v[4 * g + 3]));
+        }
+      }
+    } else if (EPI == EPI_MEAN_T) {
+      const float k0 = (t0 < H) ? 1.f : 0.f, k1 = (t0 + 1 < H) ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cs[i] += k0 * fmaxf(acc0[i], 0.f) + k1 * fmaxf(acc1[i], 0.f);
+    } else if (EPI == EPI_RAW) {
+      float* o0 = a.raw_out + (((size_t)b * H + t0) * W + col) * COUT + nb + 4 * h;
+      float* o1 = o0 + (size_t)W * COUT;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (col_ok && t0 < H)
+          *(float4*)(o0 + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+        if (col_ok && t0 + 1 < H)
+          *(float4*)(o1 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+      }
+    } else {  // EPI_PLAIN
+      const bool r0ok = col_ok && t0 < H, r1ok = col_ok && t0 + 1 < H;
+      float v0[16], v1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v0[i] = a.relu ? fmaxf(acc0[i], 0.f) : acc0[i];
+        v1[i] = a.relu ? fmaxf(acc1[i], 0.f) : acc1[i];
+      }
+      if (STATS) {
+        const float m0 = r0ok ? 1.f : 0.f, m1 = r1ok ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          st1[i] += m0 * v0[i] + m1 * v1[i];
+          st2[i] += m0 * v0[i] * v0[i] + m1 * v1[i] * v1[i];
+        }
+      }
+      T* o0 = (T*)a.out + (((size_t)b * H + t0) * W + col) * COUT + nb;
+      T* o1 = o0 + (size_t)W * COUT;
+      if (sizeof(T) == 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (r0ok) *(float4*)((float*)o0 + 8 * g + 4 * h) = make_float4(v0[4 * g], v0[4 * g + 1], v0[4 * g + 2], v0[4 * g + 3]);
+          if (r1ok) *(float4*)((float*)o1 + 8 * g + 4 * h) = make_float4(v1[4 * g], v1[4 * g + 1], v1[4 * g + 2], v1[4 * g + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          unsigned a0 = pack_bf16x2(v0[4 * g], v0[4 * g + 1]), a1 = pack_bf16x2(v0[4 * g + 2], v0[4 * g + 3]);
+          unsigned b0 = pack_bf16x2(v0[4 * g + 4], v0[4 * g + 5]), b1 = pack_bf16x2(v0[4 * g + 6], v0[4 * g + 7]);
+          auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          if (r0ok) *(uint4*)((bf16_t*)o0 + 8 * g + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          a0 = pack_bf16x2(v1[4 * g], v1[4 * g + 1]); a1 = pack_bf16x2(v1[4 * g + 2], v1[4 * g + 3]);
+          b0 = pack_bf16x2(v1[4 * g + 4], v1[4 * g + 5]); b1 = pack_bf16x2(v1[4 * g + 6], v1[4 * g + 7]);
+          s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          if (r1ok) *(uint4*)((bf16_t*)o1 + 8 * g + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+    }
+  };
+
+  // one iteration at ring phase PH: prefetch block it+2, run this wave's units, publish the prefetched block
+  auto iteration = [&](auto ph_c, int it) {
+    constexpr int PH = decltype(ph_c)::value;
+    const bool pf = (it + 1 < niter);
+    if (pf) {
+      if (DMA) stage_dma(it + 2, (PH + 2) % 3); else stage_load(it + 2);
+    }
 #pragma unroll
     for (int uu = 0; uu < C::UPW; ++uu) {
-      const int u = uu * MG + mg;
-      const int rp = u / MT, m = u - rp * MT;
-      f32x16_t acc0, acc1;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-      if (ACCIN) {
-        const int t0i = BR * it + 2 * rp, cb = f0 + 32 * m + 4 * h;
-        const float* i0 = a.acc_in + (((size_t)b * H + t0i) * W + cb) * COUT + n;
-        const int rowstride = W * COUT;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int dcol = (i & 3) + 8 * (i >> 2);
-          if (cb + dcol < W) {
-            if (t0i < H) acc0[i] = i0[dcol * COUT];
-            if (t0i + 1 < H) acc1[i] = i0[rowstride + dcol * COUT];
-          }
-        }
-      }
-
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {  // input row key q = BR*it + 2*rp + i  (input row t = q - 1)
-        const int q2 = 2 * rp + i;
-        const int ringrow = ((q2 >= BR) ? blk1 : blk0) * BR + (q2 & (BR - 1));
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int p = ringrow * SLOTS + 32 * m + r + dx;
-          const int s = lds_swz<PB>(p);
-          const char* base = smem + p * PB;
-#pragma unroll
-          for (int kg = 0; kg < NKG; ++kg) {
-            const uint4 av = *(const uint4*)(base + (((2 * kg + h) ^ s) << 4));
-            if (i <= 2) acc0 = Mma<T>::run(av, w[i * 3 + dx][kg], acc0);
-            if (i >= 1) acc1 = Mma<T>::run(av, w[(i - 1) * 3 + dx][kg], acc1);
-          }
-        }
-      }
-
-      // ---- fused epilogue: + folded bias, ReLU, pool / time-sum.  Register i of the accumulator is pixel column
-      // colbase + dcol(i), dcol(i) = (i&3) + 8*(i>>2); addresses are one per-lane base pointer + scalar offsets.
-      const int t0 = BR * it + 2 * rp;  // pre-pool rows t0, t0+1
-      const int colbase = f0 + 32 * m + 4 * h;
-      if (EPI == EPI_POOL_H2) {
-        const int Ho = H >> 1, to = t0 >> 1;
-        if (to < Ho) {
-          T* o0 = (T*)a.out + (((size_t)b * Ho + to) * W + colbase) * COUT + n;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int dcol = (i & 3) + 8 * (i >> 2);
-            const float v = 0.5f * (fmaxf(acc0[i] + bv, 0.f) + fmaxf(acc1[i] + bv, 0.f));
-            if (colbase + dcol < W) o0[dcol * COUT] = cvt_out<T>(v);
-          }
-        }
-      } else if (EPI == EPI_POOL_2X2) {
-        const int Ho = H >> 1, Wo = W >> 1, to = t0 >> 1;
-        if (to < Ho) {
-          T* o0 = (T*)a.out + (((size_t)b * Ho + to) * Wo + (colbase >> 1)) * COUT + n;
-#pragma unroll
-          for (int i = 0; i < 16; i += 2) {
-            const int dfo = ((i & 3) + 8 * (i >> 2)) >> 1;
-            const float v = 0.25f * (fmaxf(acc0[i] + bv, 0.f) + fmaxf(acc0[i + 1] + bv, 0.f) +
-                                     fmaxf(acc1[i] + bv, 0.f) + fmaxf(acc1[i + 1] + bv, 0.f));
-            if ((colbase >> 1) + dfo < Wo) o0[dfo * COUT] = cvt_out<T>(v);
-          }
-        }
-      } else if (EPI == EPI_MEAN_T) {
-        const float k0 = (t0 < H) ? 1.f : 0.f, k1 = (t0 + 1 < H) ? 1.f : 0.f;
-#pragma unroll
-        for (int mm = 0; mm < MT; ++mm)
-          if (mm == m) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-              cs[mm][i] += k0 * fmaxf(acc0[i] + bv, 0.f) + k1 * fmaxf(acc1[i] + bv, 0.f);
-          }
-      } else if (EPI == EPI_RAW) {
-        float* o0 = a.raw_out + (((size_t)b * H + t0) * W + colbase) * COUT + n;
-        const int rowstride = W * COUT;
-        const bool r0ok = t0 < H, r1ok = t0 + 1 < H;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int dcol = (i & 3) + 8 * (i >> 2);
-          if (colbase + dcol < W) {
-            if (r0ok) o0[dcol * COUT] = acc0[i];
-            if (r1ok) o0[rowstride + dcol * COUT] = acc1[i];
-          }
-        }
-      } else {  // EPI_PLAIN
-        T* o0 = (T*)a.out + (((size_t)b * H + t0) * W + colbase) * COUT + n;
-        const int rowstride = W * COUT;
-        const bool r0ok = t0 < H, r1ok = t0 + 1 < H;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int dcol = (i & 3) + 8 * (i >> 2);
-          float v0 = acc0[i] + bv, v1 = acc1[i] + bv;
-          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          if (colbase + dcol < W) {
-            if (r0ok) { o0[dcol * COUT] = cvt_out<T>(v0); st1 += v0; st2 = fmaf(v0, v0, st2); }
-            if (r1ok) { o0[rowstride + dcol * COUT] = cvt_out<T>(v1); st1 += v1; st2 = fmaf(v1, v1, st2); }
-          }
+      if (MG == 1) {
+        if (uu == 0) unit(ph_c, std::integral_constant<int, 0>{}, it);
+        if (uu == 1) unit(ph_c, std::integral_constant<int, 1>{}, it);
+      } else {  // MG == 2: row pair uu*2 + mg, dispatched on the (wave-uniform) M group
+        if (mg == 0) {
+          if (uu == 0) unit(ph_c, std::integral_constant<int, 0>{}, it);
+          if (uu == 1) unit(ph_c, std::integral_constant<int, 2>{}, it);
+        } else {
+          if (uu == 0) unit(ph_c, std::integral_constant<int, 1>{}, it);
+          if (uu == 1) unit(ph_c, std::integral_constant<int, 3>{}, it);
         }
       }
     }
-
-    if (pf && !DMA) stage_store(blk2);
+    if (pf && !DMA) stage_store((PH + 2) % 3);
     __syncthreads();
-    blk0 = blk1;
+  };
+  static_assert(C::UPW <= 2 && MG <= 2, "unit dispatch above covers UPW <= 2, MG <= 2");
+
+  for (int it = 0; it < niter; it += 3) {
+    iteration(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
+    if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
   }
 
-  if (EPI == EPI_PLAIN) {
-    if (a.stats_partial) {  // lanes r and r+32 hold the same channel; M-group waves too: combine through LDS
-      st1 += __shfl_xor(st1, 32, 64);
-      st2 += __shfl_xor(st2, 32, 64);
-      float* red = (float*)smem;
-      if (h == 0) { red[((mg * NSL + nsl) * 32 + r) * 2] = st1; red[((mg * NSL + nsl) * 32 + r) * 2 + 1] = st2; }
-      __syncthreads();
-      if (tid < NSL * 32) {
-        float s1 = 0.f, s2 = 0.f;
+  if (STATS && a.stats_partial) {
+    // per-channel sums: reduce over the 32 pixel lanes of each half-wave, then over the M groups through LDS
 #pragma unroll
-        for (int g = 0; g < MG; ++g) { s1 += red[(g * NSL * 32 + tid) * 2]; s2 += red[(g * NSL * 32 + tid) * 2 + 1]; }
-        float* dst = a.stats_partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * (NSL * 32) + tid) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        st1[i] += __shfl_xor(st1[i], off, 64);
+        st2[i] += __shfl_xor(st2[i], off, 64);
       }
+    }
+    float* red = (float*)(smem + C::RING_BYTES + C::BIAS_BYTES);
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
+        red[((mg * NSL + nsl) * 32 + c) * 2] = st1[i];
+        red[((mg * NSL + nsl) * 32 + c) * 2 + 1] = st2[i];
+      }
+    }
+    __syncthreads();
+    if (tid < NSL * 32) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int g = 0; g < MG; ++g) { s1 += red[(g * NSL * 32 + tid) * 2]; s2 += red[(g * NSL * 32 + tid) * 2 + 1]; }
+      float* dst = a.stats_partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * (NSL * 32) + tid) * 2;
+      dst[0] = s1;
+      dst[1] = s2;
     }
   }
   if (EPI == EPI_MEAN_T) {
-    // column sums -> LDS [channel][column] (ring is free after the last barrier) -> coalesced rows of emb
-    float* ef = (float*)smem;
-    constexpr int LDW = C::EPI_LDW;
+    // embedding rows: for each channel the 32 lanes of a half-wave hold 32 consecutive feature columns
+    if (col_ok) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        ef[(nsl * 32 + r) * LDW + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h] = cs[m][i] * a.inv_h;
-    __syncthreads();
-    for (int e = tid; e < NSL * 32 * 32 * MT; e += NT) {
-      const int nn = e / (32 * MT), col = e - nn * (32 * MT);
-      const int f = f0 + col;
-      if (f < W) a.emb[((size_t)b * COUT + cout_base + nn) * W + f] = ef[nn * LDW + col];
+      for (int i = 0; i < 16; ++i) {
+        const int c = nb + (i & 3) + 8 * (i >> 2) + 4 * h;
+        a.emb[((size_t)b * COUT + c) * W + col] = cs[i] * a.inv_h;
+      }
     }
   }
 }
 
-// host-side launcher (defined per instantiation in conv3x3_inst_*.hip)
-template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false>
+// host-side launcher
+template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false,
+          bool STATS = false>
 hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
-  using C = ConvCfg<T, CIN, NSL, MG, RP, MT, EPI>;
+  using C = ConvCfg<T, CIN, NSL, MG, RP, EPI>;
   ConvArgs a = a0;
-  a.nstrips = (a.W + 32 * MT - 1) / (32 * MT);
-  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN, DMA>;
+  a.nstrips = (a.W + 31) / 32;
+  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN, DMA, STATS>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

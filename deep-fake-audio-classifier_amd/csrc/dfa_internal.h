@@ -75,7 +75,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
-  int conv_dma = 0;            // stage conv inputs with global_load_lds (1) or through registers (0)
+  int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
   dfa::CaeState cae;
@@ -132,7 +132,8 @@ hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, con
                              const float* var, float* w1, float* b1, int cout, hipStream_t s);
 hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
                                     const float* mean, const float* var, int cin_total, int cin_off, int cin, int cout,
-                                    int prec, uint4* wpack, float* bias, hipStream_t s, int fold = 1);
+                                    int prec, uint4* wpack, float* bias, hipStream_t s, int fold = 1,
+                                    float post_scale = 1.0f);
 hipError_t launch_pack_conv3x3_dgrad(const float* w, int cin, int cout, int co_off, int co_n, int prec, uint4* wpack,
                                      float* bias, hipStream_t s);
 hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float* g, const float* beta,
@@ -163,7 +164,8 @@ hipError_t launch_cae_latent_export(const void* lat, int prec, float* out, int B
 // train_elem.hip / train_conv1.hip / wgrad_mfma.hip
 hipError_t launch_bn_finalize(const float* partial, int nparts, int C, double n, float* mean, float* var, float* invstd,
                               float* running_mean, float* running_var, float momentum, hipStream_t s);
-hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s);
+hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s,
+                                  float* scratch = nullptr);
 hipError_t launch_reduce_partials_strided(const float* partial, int nparts, int stride, int off, int n, float* out,
                                           hipStream_t s);
 hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,

@@ -32,7 +32,7 @@ __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const floa
                                          const float* __restrict__ g, const float* __restrict__ beta,
                                          const float* __restrict__ mean, const float* __restrict__ var,
                                          int cin_total, int cin_off, int cin, int cout, uint4* __restrict__ wpack,
-                                         float* __restrict__ bias, int fold) {
+                                         float* __restrict__ bias, int fold, float post_scale) {
   constexpr int KG = 32 / (int)sizeof(T);
   constexpr int EPL = KG / 2;  // elements per lane per k-group
   const int nkg = cin / KG;
@@ -40,8 +40,9 @@ __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const floa
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cout) {
     // fold == 0: raw convolution (train mode: BN uses batch statistics and runs as its own pass)
+    // post_scale: the average-pool factor (1/2, 1/4) of the fused epilogue, folded in: relu(s*x) = s*relu(x), s > 0
     const float s = fold ? g[i] / sqrtf(var[i] + kBnEps) : 1.f;
-    bias[i] = fold ? (b[i] - mean[i]) * s + beta[i] : b[i];
+    bias[i] = (fold ? (b[i] - mean[i]) * s + beta[i] : b[i]) * post_scale;
   }
   if (i >= total) return;
   const int lane = i & 63;
@@ -56,7 +57,7 @@ __global__ void fold_pack_conv3x3_kernel(const float* __restrict__ w, const floa
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
     const int ci = KG * kg + EPL * hh + j;
-    v[j] = cvt_out<T>(w[((size_t)co * cin_total + cin_off + ci) * 9 + tap] * s);
+    v[j] = cvt_out<T>(w[((size_t)co * cin_total + cin_off + ci) * 9 + tap] * s * post_scale);
   }
   wpack[i] = *reinterpret_cast<const uint4*>(v);
 }
@@ -71,17 +72,17 @@ hipError_t launch_fold_conv1(const float* w, const float* b, const float* g, con
 
 hipError_t launch_fold_pack_conv3x3(const float* w, const float* b, const float* g, const float* beta,
                                     const float* mean, const float* var, int cin_total, int cin_off, int cin, int cout,
-                                    int prec, uint4* wpack, float* bias, hipStream_t s, int fold) {
+                                    int prec, uint4* wpack, float* bias, hipStream_t s, int fold, float post_scale) {
   const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
   int total = (cout / 32) * 9 * (cin / kg) * 64;
   if (total < cout) total = cout;
   dim3 grid((total + 255) / 256), block(256);
   if (prec == DFA_PREC_BF16)
     hipLaunchKernelGGL(fold_pack_conv3x3_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin_total, cin_off,
-                       cin, cout, wpack, bias, fold);
+                       cin, cout, wpack, bias, fold, post_scale);
   else
     hipLaunchKernelGGL(fold_pack_conv3x3_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin_total, cin_off, cin,
-                       cout, wpack, bias, fold);
+                       cout, wpack, bias, fold, post_scale);
   return hipGetLastError();
 }
 

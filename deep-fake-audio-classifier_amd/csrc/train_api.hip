@@ -63,7 +63,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   p.sums = take((32 + 64 + 128) * 2 * 4 + 320 * 4);  // (S1,S2) per layer + conv1 wgrad record
   const int nstrips = (F + 31) / 32;
   size_t pb = (size_t)B * nstrips * 128 * 2 * 4;                              // conv stats partials
-  pb = std::max(pb, (size_t)conv1_train_blocks(B, T, F) * 320 * 4);          // conv1 passes
+  pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 320 * 4);   // conv1 passes + 2nd-level scratch
   int ppb;
   pb = std::max(pb, (size_t)bn_bwd_blocks(B, p.H1, F, &ppb) * 128 * 2 * 4);  // BN backward partials
   pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 128) * 4);   // weight-gradient partials
@@ -240,11 +240,12 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   const int nb1 = conv1_train_blocks(B, T, F);
   DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
                                         nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s));
-  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm1, s));
+  float* scratch = partial + (size_t)nb1 * 320;
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm1, s, scratch));
   hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm1, grads[2], grads[3], 32);
   DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_WGRAD, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
                                         sm1, ws + pl.da1, prec, partial, B, T, F, dc, s));
-  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, c1rec, s));
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, c1rec, s, scratch));
   hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, c1rec, grads[0], grads[1]);
   DFA_HIP_CHECK(ctx, hipGetLastError());
   return DFA_OK;

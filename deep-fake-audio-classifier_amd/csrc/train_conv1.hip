@@ -40,15 +40,9 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
   __shared__ float xs[C1T_R + 2][C1T_C + 3];
   __shared__ float red[8][32][NV];
   const int tid = threadIdx.x, c = tid & 31, pl = tid >> 5;
-  const int b = blockIdx.z, t0 = blockIdx.y * C1T_R, f0 = blockIdx.x * C1T_C;
+  const int b = blockIdx.z, f0 = blockIdx.x * C1T_C;
   const TX* xb = x + (int64_t)b * sb;
   const bool t_fast = (st == 1);
-  for (int e = tid; e < (C1T_R + 2) * (C1T_C + 2); e += 256) {
-    int rr, cc;
-    if (t_fast) { cc = e / (C1T_R + 2); rr = e - cc * (C1T_R + 2); } else { rr = e / (C1T_C + 2); cc = e - rr * (C1T_C + 2); }
-    const int t = t0 - 1 + rr, f = f0 - 1 + cc;
-    xs[rr][cc] = (t >= 0 && t < Tt && f >= 0 && f < F) ? ldx<TX>(xb + (int64_t)t * st + (int64_t)f * sf) : 0.f;
-  }
   float wk[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
@@ -59,8 +53,17 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
   float acc[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) acc[j] = 0.f;
-  __syncthreads();
   const int Ho = Tt >> 1;
+  // the block walks its share of the 8-row tiles of this (utterance, 64-column strip): blockIdx.y, +gridDim.y, ...
+  for (int t0 = blockIdx.y * C1T_R; t0 < Tt; t0 += gridDim.y * C1T_R) {
+  __syncthreads();
+  for (int e = tid; e < (C1T_R + 2) * (C1T_C + 2); e += 256) {
+    int rr, cc;
+    if (t_fast) { cc = e / (C1T_R + 2); rr = e - cc * (C1T_R + 2); } else { rr = e / (C1T_C + 2); cc = e - rr * (C1T_C + 2); }
+    const int t = t0 - 1 + rr, f = f0 - 1 + cc;
+    xs[rr][cc] = (t >= 0 && t < Tt && f >= 0 && f < F) ? ldx<TX>(xb + (int64_t)t * st + (int64_t)f * sf) : 0.f;
+  }
+  __syncthreads();
   for (int p = pl; p < C1T_R * C1T_C; p += 8) {
     const int rr = p / C1T_C, cc = p - rr * C1T_C;
     const int t = t0 + rr, f = f0 + cc;
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
       }
     }
   }
+  }
 #pragma unroll
   for (int j = 0; j < NV; ++j) red[pl][c][j] = acc[j];
   __syncthreads();
@@ -114,13 +118,14 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
   }
 }
 
-int conv1_train_blocks(int B, int T, int F) { return B * ((T + C1T_R - 1) / C1T_R) * ((F + C1T_C - 1) / C1T_C); }
+constexpr int C1T_GY = 4;  // row-tile walkers per (utterance, column strip)
+int conv1_train_blocks(int B, int T, int F) { (void)T; return B * C1T_GY * ((F + C1T_C - 1) / C1T_C); }
 
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
                               int T, int F, const DropCfg& dc, hipStream_t s) {
-  dim3 grid((F + C1T_C - 1) / C1T_C, (T + C1T_R - 1) / C1T_R, B), block(256);
+  dim3 grid((F + C1T_C - 1) / C1T_C, C1T_GY, B), block(256);
   const float inv_n = (float)(1.0 / ((double)B * T * F));
 #define DFA_C1T(TXX, TT, MODE)                                                                                        \
   hipLaunchKernelGGL((conv1_train_kernel<TXX, TT, MODE>), grid, block, 0, s, (const TXX*)x, sb, st, sf, w, bconv, mean, \

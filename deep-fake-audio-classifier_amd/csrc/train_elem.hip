@@ -71,14 +71,26 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-// generic fixed-order reduction of partial[k][n] over k (fp64 accumulate), out[j] = scale * sum
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int n, float scale,
-                                       float* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// generic fixed-order reduction of partial[k][n] over k (fp64 accumulate), out[j] = scale * sum.
+// Block = 32 outputs x 8 k-lanes (coalesced 128-byte rows); grid.y splits k into chunks whose sums go to a second
+// level (stage2 != nullptr) that a final launch of the same kernel adds up: always the same order -> deterministic.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int n,
+                                                              float scale, float* __restrict__ out, int chunk) {
+  __shared__ double red[8][33];
+  const int jl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
+  const int k0 = blockIdx.y * chunk, k1 = min(nparts, k0 + chunk);
   double s = 0.0;
-  for (int k = 0; k < nparts; ++k) s += (double)partial[(size_t)k * n + j];
-  out[j] = (float)(s * (double)scale);
+  if (j < n)
+    for (int k = k0 + kl; k < k1; k += 8) s += (double)partial[(size_t)k * n + j];
+  red[kl][jl] = s;
+  __syncthreads();
+  if (kl == 0 && j < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][jl];
+    out[(size_t)blockIdx.y * n + j] = (float)(t * (double)scale);
+  }
 }
 
 // out[j] = sum_k partial[k*stride + off + j]
@@ -323,8 +335,17 @@ hipError_t launch_bn_finalize(const float* partial, int nparts, int C, double n,
   return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, n, scale, out);
+// scratch: >= 64 * n floats, only needed when nparts > 2048 (second reduction level)
+hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s,
+                                  float* scratch) {
+  const int gx = (n + 31) / 32;
+  if (nparts <= 2048 || !scratch) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, partial, nparts, n, scale, out, nparts);
+    return hipGetLastError();
+  }
+  const int nchunks = 64, chunk = (nparts + nchunks - 1) / nchunks;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, nchunks), dim3(256), 0, s, partial, nparts, n, 1.0f, scratch, chunk);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, scratch, nchunks, n, scale, out, nchunks);
   return hipGetLastError();
 }
 
@@ -388,7 +409,7 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
                        beta, demb, (const TT*)da, partial, B, H, W, C, dc, ppb);                                       \
     hipError_t e = hipGetLastError();                                                                                  \
     if (e != hipSuccess) return e;                                                                                     \
-    e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s);                                                   \
+    e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s, nullptr);                                                   \
     if (e != hipSuccess) return e;                                                                                     \
     if (dz)                                                                                                            \
       hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \

@@ -63,7 +63,8 @@ int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out);
 int dfa_ctx_destroy(dfa_ctx* ctx);
 int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
 /* tuning switches; "conv_dma" = 1 stages the MFMA convolutions' input rows with LDS-DMA (global_load_lds) instead of
- * through registers (also settable with the environment variable DFA_CONV_DMA=1 before dfa_ctx_create) */
+ * through registers, 0 forces register staging, -1 (default) picks per kernel (also settable with the environment
+ * variable DFA_CONV_DMA=0|1 before dfa_ctx_create) */
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value);
 const char* dfa_last_error(const dfa_ctx* ctx);
 const char* dfa_error_name(int code);
