@@ -27,6 +27,25 @@ __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf16_to_float(*p); }
 
+template <typename T>
+__device__ __forceinline__ void ld8f(const T* p, float* v);
+template <>
+__device__ __forceinline__ void ld8f<float>(const float* p, float* v) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ld8f<bf16_t>(const bf16_t* p, float* v) {
+  const uint4 q = *reinterpret_cast<const uint4*>(p);
+  const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(u[e] << 16); v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+}
+
+// Thread = (pixel lane, channel octet): lanes 4p..4p+3 own the four 8-channel groups of a pixel, so the upstream
+// gradient da1 is one 16/32-byte load per thread, the dropout mask costs two Philox calls per 8 elements, and the x taps
+// are LDS broadcasts.  Every thread keeps its 8 channels' weights, BN constants and accumulators in registers and walks
+// 8 pixels of each 8 x 64 tile; sums are combined across the 64 pixel lanes at the end (shuffles, then LDS).
 template <typename TX, typename T, int MODE>
 __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__ x, int64_t sb, int64_t st, int64_t sf,
                                                           const float* __restrict__ w, const float* __restrict__ bconv,
@@ -38,83 +57,112 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
                                                           int F, DropCfg dc, float inv_n) {
   constexpr int NV = (MODE == C1M_WGRAD) ? 10 : 2;
   __shared__ float xs[C1T_R + 2][C1T_C + 3];
-  __shared__ float red[8][32][NV];
-  const int tid = threadIdx.x, c = tid & 31, pl = tid >> 5;
+  __shared__ float red[4][4][8 * NV];
+  const int tid = threadIdx.x, q = tid & 3, pl = tid >> 2;
   const int b = blockIdx.z, f0 = blockIdx.x * C1T_C;
   const TX* xb = x + (int64_t)b * sb;
   const bool t_fast = (st == 1);
-  float wk[9];
+  float wk[8][9], bc[8];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-  const float bc = bconv[c];
-  float mu = 0.f, is = 0.f, gm = 0.f, bt = 0.f, s1n = 0.f, s2n = 0.f;
-  if (MODE != C1M_STATS) { mu = mean[c]; is = invstd[c]; gm = gamma[c]; bt = beta[c]; }
-  if (MODE == C1M_WGRAD) { s1n = sums[2 * c] * inv_n; s2n = sums[2 * c + 1] * inv_n; }
-  float acc[NV];
+  for (int c = 0; c < 8; ++c) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+    for (int k = 0; k < 9; ++k) wk[c][k] = w[(q * 8 + c) * 9 + k];
+    bc[c] = bconv[q * 8 + c];
+  }
+  // BN constants folded per channel: xhat = z*is - mu*is;  y > 0 test on gm*xhat + bt;  dz = ga*(dy - s1n - xhat*s2n)
+  float is[8], mis[8], gm[8], bt[8], ga[8], s1n[8], s2n[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ch = q * 8 + c;
+    is[c] = mis[c] = gm[c] = bt[c] = ga[c] = s1n[c] = s2n[c] = 0.f;
+    if (MODE != C1M_STATS) { is[c] = invstd[ch]; mis[c] = mean[ch] * is[c]; gm[c] = gamma[ch]; bt[c] = beta[ch]; }
+    if (MODE == C1M_WGRAD) { ga[c] = gm[c] * is[c]; s1n[c] = sums[2 * ch] * inv_n; s2n[c] = sums[2 * ch + 1] * inv_n; }
+  }
+  float acc[8][NV];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[c][j] = 0.f;
   const int Ho = Tt >> 1;
   // the block walks its share of the 8-row tiles of this (utterance, 64-column strip): blockIdx.y, +gridDim.y, ...
   for (int t0 = blockIdx.y * C1T_R; t0 < Tt; t0 += gridDim.y * C1T_R) {
-  __syncthreads();
-  for (int e = tid; e < (C1T_R + 2) * (C1T_C + 2); e += 256) {
-    int rr, cc;
-    if (t_fast) { cc = e / (C1T_R + 2); rr = e - cc * (C1T_R + 2); } else { rr = e / (C1T_C + 2); cc = e - rr * (C1T_C + 2); }
-    const int t = t0 - 1 + rr, f = f0 - 1 + cc;
-    xs[rr][cc] = (t >= 0 && t < Tt && f >= 0 && f < F) ? ldx<TX>(xb + (int64_t)t * st + (int64_t)f * sf) : 0.f;
-  }
-  __syncthreads();
-  for (int p = pl; p < C1T_R * C1T_C; p += 8) {
-    const int rr = p / C1T_C, cc = p - rr * C1T_C;
-    const int t = t0 + rr, f = f0 + cc;
-    if (t >= Tt || f >= F) continue;
-    float xv[9];
+    __syncthreads();
+    for (int e = tid; e < (C1T_R + 2) * (C1T_C + 2); e += 256) {
+      int rr, cc;
+      if (t_fast) { cc = e / (C1T_R + 2); rr = e - cc * (C1T_R + 2); } else { rr = e / (C1T_C + 2); cc = e - rr * (C1T_C + 2); }
+      const int t = t0 - 1 + rr, f = f0 - 1 + cc;
+      xs[rr][cc] = (t >= 0 && t < Tt && f >= 0 && f < F) ? ldx<TX>(xb + (int64_t)t * st + (int64_t)f * sf) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int rr = 0; rr < C1T_R; ++rr) {
+      const int t = t0 + rr, f = f0 + pl;
+      if (t >= Tt || f >= F) continue;
+      float xv[9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xs[rr + dy][cc + dx];
-    float z = bc;
+        for (int dx = 0; dx < 3; ++dx) xv[dy * 3 + dx] = xs[rr + dy][pl + dx];
+      float g[8];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) z = fmaf(wk[k], xv[k], z);
-    if (MODE == C1M_STATS) {
-      acc[0] += z;
-      acc[1] = fmaf(z, z, acc[1]);
-    } else {
-      const float xh = (z - mu) * is;
-      float dy = 0.f;
+      for (int c = 0; c < 8; ++c) g[c] = 0.f;
       const int to = t >> 1;
-      if (to < Ho && fmaf(gm, xh, bt) > 0.f) {
-        const size_t idx = (((size_t)b * Ho + to) * F + f) * 32 + c;
-        float g = 0.5f * ldf<T>(da1 + idx);
-        if (dc.thresh != 0) {
-          float ds[8];
-          drop_scale8(dc, idx & ~(size_t)7, ds);
-          g *= ds[c & 7];
-        }
-        dy = g;
-      }
-      if (MODE == C1M_BWD_REDUCE) {
-        acc[0] += dy;
-        acc[1] = fmaf(dy, xh, acc[1]);
-      } else {
-        const float dz = gm * is * (dy - s1n - xh * s2n);
+      if (MODE != C1M_STATS && to < Ho) {
+        const size_t idx = (((size_t)b * Ho + to) * F + f) * 32 + q * 8;
+        float d[8], ds[8];
+        ld8f<T>(da1 + idx, d);
+        drop_scale8(dc, idx, ds);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] = fmaf(dz, xv[k], acc[k]);
-        acc[9] += dz;
+        for (int c = 0; c < 8; ++c) g[c] = 0.5f * d[c] * ds[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float z = bc[c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) z = fmaf(wk[c][k], xv[k], z);
+        if (MODE == C1M_STATS) {
+          acc[c][0] += z;
+          acc[c][1] = fmaf(z, z, acc[c][1]);
+        } else {
+          const float xh = fmaf(z, is[c], -mis[c]);
+          const float dy = (fmaf(gm[c], xh, bt[c]) > 0.f) ? g[c] : 0.f;
+          if (MODE == C1M_BWD_REDUCE) {
+            acc[c][0] += dy;
+            acc[c][1] = fmaf(dy, xh, acc[c][1]);
+          } else {
+            const float dz = ga[c] * (dy - s1n[c] - xh * s2n[c]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[c][k] = fmaf(dz, xv[k], acc[c][k]);
+            acc[c][NV - 1] += dz;
+          }
+        }
       }
     }
   }
-  }
+  // combine the 16 pixel lanes of each wave that share an octet (lane bits 2..5), then the 4 waves through LDS
 #pragma unroll
-  for (int j = 0; j < NV; ++j) red[pl][c][j] = acc[j];
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float v = acc[c][j];
+#pragma unroll
+      for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      acc[c][j] = v;
+    }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 4) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) red[wave][lane][c * NV + j] = acc[c][j];
+  }
   __syncthreads();
   const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  for (int e = tid; e < 32 * NV; e += 256) {
-    const int cc = e / NV, j = e - cc * NV;
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += red[q][cc][j];
-    partial[blk * (32 * NV) + e] = s;
+  for (int e = tid; e < 32 * NV; e += 256) {   // e = channel * NV + j, channel = octet * 8 + c
+    const int ch = e / NV, j = e - ch * NV;
+    const int qq = ch >> 3, c = ch & 7;
+    partial[blk * (32 * NV) + e] = (red[0][qq][c * NV + j] + red[1][qq][c * NV + j]) +
+                                   (red[2][qq][c * NV + j] + red[3][qq][c * NV + j]);
   }
 }
 
