@@ -132,6 +132,30 @@ def cpu_baseline(torch, sd_cpu, seconds):
                       "oracle/torch_ref.py (plain PyTorch CPU ops restating src/model.py:33-42)"}
 
 
+def train_step_metric(torch, device, B, steps=6, warmup=2):
+    """Secondary metric (BASELINE configs[2]): CNN2D training step (fwd + bwd + fused AdamW, dropout 0.2, label
+    smoothing 0.05) in the bf16-storage mode, utterances/s on this rank."""
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import NativeTrainer
+    torch.manual_seed(0)
+    model = CNN2D(in_features=F, dropout=0.2, precision="bf16").to(device)
+    g = torch.Generator().manual_seed(99)
+    x = (torch.randn(B, F, T, generator=g) * 3.2 - 0.07).to(device=device, dtype=torch.bfloat16).transpose(1, 2)
+    y = (torch.rand(B, generator=g) > 0.5).float().to(device)
+    tr = NativeTrainer(model, label_smoothing=0.05)
+    for _ in range(warmup):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
+            "batch_per_gpu": B, "loss": round(float(loss.item()), 4),
+            "what": "fwd + bwd + fused AdamW, dropout 0.2, label smoothing 0.05 (src/train.py:71-76), 1 GPU"}
+
+
 def main():
     args = parse_args()
     import torch
@@ -200,6 +224,8 @@ def main():
                             "max_abs_logit_diff_vs_bf16": round(max(abs(a - b) for a, b in
                                                                     zip(r16["logits_sample"], r32["logits_sample"])), 5)},
         }
+        if world == 1:
+            line["train_step"] = train_step_metric(torch, device, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_seconds)
         print(json.dumps(line), flush=True)

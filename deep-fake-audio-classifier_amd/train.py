@@ -1,0 +1,250 @@
+"""Training driver -- counterpart of src/train.py (same `train_one_epoch` signature and the CLI flags that concern the
+CNN2D/CNN1D path), with the model step on the MI355X HIP path.
+
+Two step engines:
+  * reference-style (default for `train_one_epoch`): `loss = criterion(model(x)); loss.backward(); optimizer.step()`
+    with any torch criterion / optimizer -- the model's train-mode forward/backward are C-ABI calls behind a
+    torch.autograd.Function;
+  * `--native`: the whole step (forward, BCE + label smoothing, backward, one flat gradient all-reduce, fused AdamW)
+    on the C ABI via `NativeTrainer`; one process per GPU under torchrun gives data-parallel training.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import distributed as dfa_dist
+from .augmentation import channel_drop, compose, gaussian_jitter, spec_augment, time_shift
+from .dataloaders import FlatBatcher, make_loader
+from .dataset import AudioDeepfakeDataset
+from .evaluation import evaluate
+from .model import CNN2D
+from .training import save_checkpoint
+
+
+def train_one_epoch(model, dataloader, criterion, optimizer, device: str = "cuda", batch_context=None,
+                    augment_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, swap_tf: bool = False):
+    """One pass over `dataloader` (src/train.py:31-91); returns the sample-weighted mean training loss.
+    The running loss is accumulated on the device; it is synchronised to the host only when a `batch_context`
+    (progress display) asks for it, not once per batch."""
+    model.train()
+    loss_sum = None
+    count = 0
+    for batch_idx, (features, labels) in enumerate(dataloader):
+        features = features.to(device, non_blocking=True)
+        labels = labels.to(device, non_blocking=True)
+        if swap_tf:
+            features = features.transpose(1, 2)
+        if augment_fn is not None:
+            features = augment_fn(features)
+        logits = model(features).squeeze(-1)
+        loss = criterion(logits, labels)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        term = loss.detach().double() * labels.size(0)
+        loss_sum = term if loss_sum is None else loss_sum + term
+        count += labels.size(0)
+        if batch_context is not None and count > 0:
+            batch_context.update_batch(_BatchMetrics(batch_idx, float(loss_sum.item()) / count, labels.size(0)))
+    return (float(loss_sum.item()) / count) if count > 0 else None
+
+
+class _BatchMetrics:
+    def __init__(self, batch_idx, running_loss, batch_size):
+        self.batch_idx, self.running_loss, self.batch_size = batch_idx, running_loss, batch_size
+
+
+def train_one_epoch_native(trainer, batcher, augment_fn=None, swap_tf: bool = True):
+    """One pass with the all-native step; `batcher` yields (stored-layout features [b,180,321], labels [b]) on the GPU."""
+    total, count = None, 0
+    for feats, labels in batcher:
+        x = feats.transpose(1, 2) if swap_tf else feats
+        if augment_fn is not None:
+            x = augment_fn(x)
+        loss = trainer.step(x, labels)
+        term = loss.detach().double().squeeze() * labels.size(0)
+        total = term if total is None else total + term
+        count += labels.size(0)
+    return (float(total.item()) / count) if count else None
+
+
+def build_augment_fn(args):
+    fns = []
+    if args.spec_augment:
+        fns.append(lambda x: spec_augment(x, time_mask_ratio=args.time_mask_ratio,
+                                          feature_mask_ratio=args.feature_mask_ratio, apply_time_mask=True,
+                                          apply_feature_mask=args.feature_mask))
+    if args.time_shift:
+        fns.append(lambda x: time_shift(x, max_shift_ratio=args.time_shift_ratio))
+    if args.channel_drop:
+        fns.append(lambda x: channel_drop(x, drop_prob=args.channel_drop_prob))
+    if args.gaussian_jitter:
+        fns.append(lambda x: gaussian_jitter(x, std=args.gaussian_jitter_std))
+    return compose(*fns) if fns else None
+
+
+def make_criterion(label_smoothing: float):
+    if not (0.0 <= label_smoothing < 0.5):
+        raise ValueError("--label-smoothing must be in [0, 0.5)")
+    bce = nn.BCEWithLogitsLoss()
+    eps = float(label_smoothing)
+
+    def criterion(logits, y):
+        return bce(logits, y * (1.0 - eps) + 0.5 * eps if eps > 0 else y)
+    return criterion
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Train CNN2D for audio deepfake detection on MI355X.")
+    p.add_argument("--train-features", default="data/train/features.pkl")
+    p.add_argument("--train-labels", default="data/train/labels.pkl")
+    p.add_argument("--dev-features", default="data/dev/features.pkl")
+    p.add_argument("--dev-labels", default="data/dev/labels.pkl")
+    p.add_argument("--model", default="cnn2d", choices=["cnn2d"])
+    p.add_argument("--batch-size", type=int, default=32)
+    p.add_argument("--num-workers", type=int, default=2)
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--weight-decay", type=float, default=0.0)
+    p.add_argument("--early-stop", type=int, default=0)
+    p.add_argument("--lr-scheduler", default="none", choices=["none", "plateau"])
+    p.add_argument("--lr-scheduler-metric", default="dev_eer", choices=["dev_eer", "dev_loss"])
+    p.add_argument("--lr-scheduler-factor", type=float, default=0.5)
+    p.add_argument("--lr-scheduler-patience", type=int, default=2)
+    p.add_argument("--lr-scheduler-threshold", type=float, default=1e-4)
+    p.add_argument("--lr-scheduler-min-lr", type=float, default=1e-6)
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--in-features", type=int, default=180)
+    p.add_argument("--dropout", type=float, default=0.2)
+    p.add_argument("--checkpoint-dir", default="checkpoints")
+    p.add_argument("--run-name", default="")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--spec-augment", action="store_true")
+    p.add_argument("--time-mask-ratio", type=float, default=0.2)
+    p.add_argument("--feature-mask-ratio", type=float, default=0.1)
+    p.add_argument("--feature-mask", action="store_true")
+    p.add_argument("--time-shift", action="store_true")
+    p.add_argument("--time-shift-ratio", type=float, default=0.1)
+    p.add_argument("--channel-drop", action="store_true")
+    p.add_argument("--channel-drop-prob", type=float, default=0.1)
+    p.add_argument("--gaussian-jitter", action="store_true")
+    p.add_argument("--gaussian-jitter-std", type=float, default=0.01)
+    p.add_argument("--label-smoothing", type=float, default=0.0)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--native", action="store_true", help="all-native step (fused AdamW, flat-gradient all-reduce)")
+    sw = p.add_mutually_exclusive_group()
+    sw.add_argument("--swap-tf", dest="swap_tf", action="store_true")
+    sw.add_argument("--no-swap-tf", dest="swap_tf", action="store_false")
+    p.set_defaults(swap_tf=True)
+    return p.parse_args(argv)
+
+
+def set_seed(seed: int) -> None:
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    set_seed(args.seed)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local_rank) if args.device.startswith("cuda") else torch.device(args.device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    rank, world = dfa_dist.init(device=device)
+    out_dir = os.path.join(args.checkpoint_dir, args.run_name) if args.run_name else args.checkpoint_dir
+    best_path, last_path = os.path.join(out_dir, f"{args.model}_best.pt"), os.path.join(out_dir, f"{args.model}_last.pt")
+
+    model = CNN2D(in_features=args.in_features, dropout=args.dropout, precision=args.precision).to(device)
+    weight_decay = args.weight_decay if args.weight_decay > 0 else 0.01      # AdamW default of src/train.py:321-325
+    criterion = make_criterion(args.label_smoothing)
+    augment_fn = build_augment_fn(args)
+
+    if args.native or world > 1:
+        from .training.train_step import NativeTrainer
+        trainer = NativeTrainer(model, lr=args.lr, weight_decay=weight_decay, label_smoothing=args.label_smoothing)
+        dfa_dist.broadcast_parameters_(trainer.flat_p)
+        feats, labels = AudioDeepfakeDataset(args.train_features, args.train_labels).stacked(pin=True)
+        optimizer = _NativeOptimizerView(trainer)
+    else:
+        trainer = None
+        optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=weight_decay)
+        train_loader = make_loader(args.train_features, args.train_labels, batch_size=args.batch_size,
+                                   num_workers=args.num_workers, shuffle=True)
+    dev_loader = make_loader(args.dev_features, args.dev_labels, batch_size=args.batch_size,
+                             num_workers=args.num_workers, shuffle=False)
+    scheduler = None
+    if args.lr_scheduler == "plateau" and trainer is None:
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
+            optimizer, mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience,
+            threshold=args.lr_scheduler_threshold, min_lr=args.lr_scheduler_min_lr)
+
+    best_eer = best_train = best_dev = None
+    no_improve, last_epoch = 0, 0
+    for epoch in range(1, args.epochs + 1):
+        if trainer is not None:
+            perm = torch.randperm(feats.shape[0], generator=torch.Generator().manual_seed(args.seed + epoch))
+            batcher = FlatBatcher(feats[perm], labels[perm], args.batch_size, device=device, rank=rank, world=world)
+            train_loss = train_one_epoch_native(trainer, batcher, augment_fn, args.swap_tf)
+        else:
+            train_loss = train_one_epoch(model, train_loader, criterion, optimizer, device=device,
+                                         augment_fn=augment_fn, swap_tf=args.swap_tf)
+        metrics, _, _ = evaluate(model, dev_loader, criterion=criterion, device=device, swap_tf=args.swap_tf)
+        eer, dev_loss = metrics["eer"], metrics["avg_loss"]
+        is_best = False
+        if eer is not None:
+            if best_eer is None or eer < best_eer:
+                is_best, best_eer, best_train, best_dev, no_improve = True, eer, train_loss, dev_loss, 0
+            else:
+                no_improve += 1
+                if (abs(eer - best_eer) <= 1e-4 and None not in (train_loss, dev_loss, best_train, best_dev)
+                        and train_loss < best_train - 1e-6 and dev_loss < best_dev - 1e-6):
+                    is_best, best_train, best_dev = True, train_loss, dev_loss
+        if scheduler is not None:
+            metric = dev_loss if args.lr_scheduler_metric == "dev_loss" else eer
+            if metric is not None:
+                scheduler.step(metric)
+        if rank == 0:
+            print(f"epoch {epoch}: train_loss={train_loss:.6f} dev_loss={dev_loss:.6f} dev_eer={eer:.6f}"
+                  + ("  *best*" if is_best else ""))
+            if is_best:
+                save_checkpoint(model, optimizer, epoch, args, best_path, scheduler=scheduler)
+        last_epoch = epoch
+        if args.early_stop and no_improve >= args.early_stop:
+            break
+    if rank == 0:
+        save_checkpoint(model, optimizer, last_epoch, args, last_path, scheduler=scheduler)
+
+
+class _NativeOptimizerView:
+    """state_dict() of the fused optimiser in torch.optim.AdamW's format, so checkpoints stay interchangeable."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+
+    def state_dict(self):
+        t, state, off = self.t, {}, 0
+        for i, p in enumerate(t.model.parameters()):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(t.step_count)),
+                        "exp_avg": t.exp_avg[off:off + k].view_as(p).clone(),
+                        "exp_avg_sq": t.exp_avg_sq[off:off + k].view_as(p).clone()}
+            off += k
+        group = {"lr": t.lr, "betas": t.betas, "eps": t.eps, "weight_decay": t.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+
+if __name__ == "__main__":
+    main()
