@@ -42,25 +42,27 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
   const bool t_fast = (st == 1);
   constexpr int NX = (C1_XR * C1_XC + 255) / 256;   // x elements per thread per tile
   // x tile of the row tile starting at pooled row i0 -> registers (walk the contiguous axis with consecutive threads)
-  auto load_tile = [&](int i0, float* xr) {
+  auto load_tile = [&](int i0, TX* xr) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int e = k * 256 + tid;
       int rr, cc;
       if (t_fast) { cc = e / C1_XR; rr = e - cc * C1_XR; } else { rr = e / C1_XC; cc = e - rr * C1_XC; }
       const int t = 2 * i0 - 1 + rr, f = f_base + cc;
-      float v = 0.f;
-      if (e < C1_XR * C1_XC && t >= 0 && t < T && f >= 0 && f < F) v = load_x<TX>(xb + (int64_t)t * st + (int64_t)f * sf);
-      xr[k] = v;
+      // branch-free: always load from a clamped in-image address, zero afterwards -- the NX loads issue back to back
+      const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
+      xr[k] = xb[(int64_t)tc * st + (int64_t)fc * sf];   // raw bits only: the first USE (and its wait) is in store_tile
     }
   };
-  auto store_tile = [&](int buf, const float* xr) {
+  auto store_tile = [&](int buf, int i0, const TX* xr) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int e = k * 256 + tid;
       int rr, cc;
       if (t_fast) { cc = e / C1_XR; rr = e - cc * C1_XR; } else { rr = e / C1_XC; cc = e - rr * C1_XC; }
-      if (e < C1_XR * C1_XC) xs[buf][rr][cc] = xr[k];
+      const int t = 2 * i0 - 1 + rr, f = f_base + cc;
+      const bool ok = t >= 0 && t < T && f >= 0 && f < F;     // conv zero padding
+      if (e < C1_XR * C1_XC) xs[buf][rr][cc] = ok ? load_x<TX>(&xr[k]) : 0.f;
     }
   };
   const int q = tid & 3, pl = tid >> 2;   // channel octet, pixel lane (0..63)
@@ -76,28 +78,29 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
   // the block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ...; the next tile's x is fetched (global -> VGPR)
   // while the current one is computed, and lands in the other LDS buffer before the single barrier of the iteration
   const int ntiles = (Ho + C1_TI - 1) / C1_TI;
-  float xr[NX];
+  TX xr[NX];
   int buf = 0;
   if ((int)blockIdx.y < ntiles) {
     load_tile(blockIdx.y * C1_TI, xr);
-    store_tile(0, xr);
+    store_tile(0, blockIdx.y * C1_TI, xr);
   }
   __syncthreads();
   for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
     const int i0 = tile * C1_TI;
     const bool more = tile + (int)gridDim.y < ntiles;
     if (more) load_tile((tile + gridDim.y) * C1_TI, xr);
-#pragma unroll 1
+    // the 4 passes keep their outputs in registers; the stores are issued after the prefetched x tile has been written to
+    // LDS, so that wait never has this iteration's stores in front of it (vmcnt counts loads and stores in order)
+    constexpr int NVS = (int)(8 * sizeof(TO) / 16);
+    uint4 outv[C1_TI / 4][NVS];
+#pragma unroll
     for (int pass = 0; pass < C1_TI / 4; ++pass) {
       const int ri = pass * 4 + rq;
-      const int i = i0 + ri;
-      if (i >= Ho || f >= F) continue;
       f32x2_t xp[4][3];   // x rows 2i-1 .. 2i+2, broadcast to both halves of the channel pair
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int d = 0; d < 3; ++d) { const float xv = xs[buf][2 * ri + a][fi + d]; xp[a][d] = (f32x2_t){xv, xv}; }
-      const uint64_t oidx = (((uint64_t)b * Ho + i) * F + f) * 32 + q * 8;
       float o[8];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -113,20 +116,28 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
         o[2 * c + 1] = 0.5f * (fmaxf(a0.y, 0.f) + fmaxf(a1.y, 0.f));
       }
       if (dc.thresh != 0) {
+        const int i = i0 + ri;
         float ds[8];
-        drop_scale8(dc, oidx, ds);
+        drop_scale8(dc, (((uint64_t)b * Ho + i) * F + f) * 32 + q * 8, ds);
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[c] *= ds[c];
       }
       TO ov[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) ov[c] = cvt_out<TO>(o[c]);
-      TO* op = out + oidx;
 #pragma unroll
-      for (int v = 0; v < (int)(8 * sizeof(TO) / 16); ++v)
-        reinterpret_cast<uint4*>(op)[v] = reinterpret_cast<const uint4*>(ov)[v];
+      for (int v = 0; v < NVS; ++v) outv[pass][v] = reinterpret_cast<const uint4*>(ov)[v];
     }
-    if (more) store_tile(buf ^ 1, xr);
+    if (more) store_tile(buf ^ 1, (tile + gridDim.y) * C1_TI, xr);
+#pragma unroll
+    for (int pass = 0; pass < C1_TI / 4; ++pass) {
+      const int i = i0 + pass * 4 + rq;
+      if (i < Ho && f < F) {
+        TO* op = out + (((uint64_t)b * Ho + i) * F + f) * 32 + q * 8;
+#pragma unroll
+        for (int v = 0; v < NVS; ++v) reinterpret_cast<uint4*>(op)[v] = outv[pass][v];
+      }
+    }
     __syncthreads();
     buf ^= 1;
   }
