@@ -143,3 +143,73 @@ def test_train_cli_end_to_end(tmp_path):
         m.load_state_dict(blob["model_state"])
         metrics, _, _ = evaluate(m, make_loader(dvf, dvl, batch_size=16, num_workers=0), device="cuda", swap_tf=True)
         assert metrics["eer"] <= 0.2, (run, metrics)            # chance is 0.5; a few epochs on 96 utterances
+
+
+def _dp_worker(rank, world, port, tmp):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import dfa_amd  # noqa: F401
+    from dfa_amd import distributed as D
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import NativeTrainer
+    torch.cuda.set_device(0)                      # both ranks share the one GPU of the test box
+    D.init(backend="gloo")                        # gloo moves CUDA tensors through the host: same code path as RCCL
+    torch.manual_seed(100 + rank)                 # different initial weights per rank on purpose ...
+    model = CNN2D(dropout=0.0).to("cuda")
+    tr = NativeTrainer(model, label_smoothing=0.05)
+    D.broadcast_parameters_(tr.flat_p)            # ... made identical by the rank-0 broadcast
+    g = torch.Generator().manual_seed(7)
+    stored = torch.randn(8, 180, 40, generator=g) * 3.2
+    y = (torch.rand(8, generator=g) > 0.5).float()
+    lo, hi = D.shard_range(8, rank, world)
+    x = stored[lo:hi].to("cuda").transpose(1, 2)
+    grads = []
+    for _ in range(3):
+        loss = tr.step(x, y[lo:hi])
+        grads.append(tr.flat_g.clone())           # after the all-reduce: the SUM over ranks
+    assert torch.isfinite(loss).all()
+    # every rank holds the same summed gradient and therefore the same parameters after every step
+    gathered = [torch.zeros_like(tr.flat_p) for _ in range(world)]
+    dist.all_gather(gathered, tr.flat_p)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    gg = [torch.zeros_like(grads[0]) for _ in range(world)]
+    dist.all_gather(gg, grads[0])
+    assert all(torch.equal(gg[0], t) for t in gg)
+    torch.save({"p": tr.flat_p.cpu(), "g0": grads[0].cpu()}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_one_gpu(tmp_path):
+    """world_size 2 on the single test GPU (gloo): broadcast of the flat parameters, ONE flat-gradient all-reduce per
+    step, 1/world folded into the fused AdamW.  The summed gradient of step 1 must equal the sum of the two shards'
+    gradients computed in this process (BatchNorm uses local batch statistics, as in DDP)."""
+    import os
+    import torch.multiprocessing as mp
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import NativeTrainer
+    port = 29600 + (os.getpid() % 1000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["p"], r1["p"])
+    # single-process check of the summed first-step gradient
+    torch.manual_seed(100)
+    model = CNN2D(dropout=0.0).to("cuda")
+    tr = NativeTrainer(model, label_smoothing=0.05)
+    g = torch.Generator().manual_seed(7)
+    stored = torch.randn(8, 180, 40, generator=g) * 3.2
+    y = (torch.rand(8, generator=g) > 0.5).float()
+    p0 = tr.flat_p.clone()
+    total = torch.zeros_like(tr.flat_g)
+    for lo, hi in ((0, 4), (4, 8)):
+        tr.flat_p.copy_(p0)
+        tr.exp_avg.zero_(); tr.exp_avg_sq.zero_(); tr.step_count = 0
+        for i in (1, 6, 11):                                     # same BN starting point for both shards
+            model.conv[i].running_mean.zero_(); model.conv[i].running_var.fill_(1.0)
+        tr.step(stored[lo:hi].to("cuda").transpose(1, 2), y[lo:hi])
+        total += tr.flat_g
+    scale = total.abs().max().item()
+    assert (r0["g0"].cuda() - total).abs().max().item() <= 1e-5 * scale + 1e-7
