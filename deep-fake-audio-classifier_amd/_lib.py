@@ -49,6 +49,12 @@ SYMBOLS = [
     ("dfa_cnn1d_prepare", C.c_int, [C.c_void_p]),
     ("dfa_cnn1d_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("dfa_cnn1d_train_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("dfa_cnn1d_forward_train", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                          C.c_int64, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_float, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("dfa_cnn1d_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                     C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
     ("dfa_cae_set_params", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     ("dfa_cae_prepare", C.c_int, [C.c_void_p, C.c_int]),
     ("dfa_cae_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,

@@ -127,6 +127,7 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   if (ctx->cnn2d.packed) (void)hipFree(ctx->cnn2d.packed);
   if (ctx->cnn2d.train_packed) (void)hipFree(ctx->cnn2d.train_packed);
   if (ctx->cnn1d.packed) (void)hipFree(ctx->cnn1d.packed);
+  if (ctx->cnn1d.train_packed) (void)hipFree(ctx->cnn1d.train_packed);
   if (ctx->cae.packed) (void)hipFree(ctx->cae.packed);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   for (auto& t : ctx->slots) {

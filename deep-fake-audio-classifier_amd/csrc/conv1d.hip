@@ -12,7 +12,7 @@ namespace dfa {
 
 constexpr int C1D_OT = 32, C1D_TT = 64, C1D_CC = 16;
 
-template <bool MEAN>
+template <bool MEAN, bool RELU = true>
 __global__ __launch_bounds__(256) void conv1d_k3_bn_relu_kernel(const float* __restrict__ x, int64_t sb, int64_t sc,
                                                                  int64_t st, const float* __restrict__ w,
                                                                  const float* __restrict__ bias,
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv1d_k3_bn_relu_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int t = t0 + 4 * tq + j;
-          if (t < T) orow[t] = fmaxf(acc[oo][j], 0.f);
+          if (t < T) orow[t] = RELU ? fmaxf(acc[oo][j], 0.f) : acc[oo][j];
         }
       }
     }
@@ -115,7 +115,12 @@ hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, co
 }
 
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
-                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s) {
+                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu) {
+  if (!relu) {   // raw convolution (+ bias): train-mode forward and the data-gradient convolution
+    hipLaunchKernelGGL((conv1d_k3_bn_relu_kernel<false, false>), dim3((T + C1D_TT - 1) / C1D_TT, Cout / C1D_OT, B), dim3(256),
+                       0, s, x, sb, sc, st, w, bias, out, Cin, Cout, T, 0.f);
+    return hipGetLastError();
+  }
   if (mean) {
     hipLaunchKernelGGL(conv1d_k3_bn_relu_kernel<true>, dim3(1, Cout / C1D_OT, B), dim3(256), 0, s, x, sb, sc, st, w,
                        bias, out, Cin, Cout, T, 1.0f / (float)T);

@@ -56,6 +56,11 @@ struct Cnn1dState {
   int in_features = 0;
   void* packed = nullptr;
   float *w[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
+  // train mode: data-gradient weight images of conv layers 2 and 3 (+ a zero bias), dropout state
+  void* train_packed = nullptr;
+  float *wt[2] = {nullptr, nullptr}, *zero_bias = nullptr;
+  DropCfg train_drop{};
+  int train_B = 0, train_T = 0;
 };
 
 struct CaeState {
@@ -150,7 +155,20 @@ hipError_t launch_linear(const float* emb, const float* w, const float* bias, fl
 hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
-                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s);
+                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu = true);
+// train_cnn1d.hip
+int cm_chunks(int B);
+hipError_t launch_cm_stats(const float* z, float* partial, int B, int C, int T, hipStream_t s);
+hipError_t launch_cm_bn_relu_drop(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* h, int B, int C, int T, const DropCfg& dc, hipStream_t s);
+hipError_t launch_cm_bn_relu_meant(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* pooled, int B, int C, int T, hipStream_t s);
+hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* up, float* partial, float* sums, float* dz, int B, int C,
+                            int T, const DropCfg& dc, hipStream_t s);
+hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
+                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s);
+hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias, int cin, int cout, hipStream_t s);
 // cae.hip
 hipError_t launch_cae_enc1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu,
                            const float* sigma, const float* w1, const float* b1, void* out, int prec, int B, int T, int F,

@@ -273,3 +273,162 @@ int dfa_adamw_step(dfa_ctx* ctx, float* param, const float* grad, float* exp_avg
 }
 
 }  // extern "C"
+
+/* ------------------------------------------------------------------------------------------------ CNN1D training */
+namespace {
+
+struct Train1dPlan {
+  size_t z[3], h[2], pooled, dpooled, dz[3], dh[2], stats, sums, partial, total;
+};
+
+Train1dPlan plan_train1d(int B, int T, int F) {
+  Train1dPlan p;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
+  const int C[3] = {32, 64, 128};
+  for (int l = 0; l < 3; ++l) p.z[l] = take((size_t)B * C[l] * T * 4);
+  for (int l = 0; l < 2; ++l) p.h[l] = take((size_t)B * C[l] * T * 4);
+  p.pooled = take((size_t)B * 128 * 4);
+  p.dpooled = take((size_t)B * 128 * 4);
+  for (int l = 0; l < 3; ++l) p.dz[l] = take((size_t)B * C[l] * T * 4);
+  for (int l = 0; l < 2; ++l) p.dh[l] = take((size_t)B * C[l] * T * 4);
+  p.stats = take((32 + 64 + 128) * 3 * 4);
+  p.sums = take((32 + 64 + 128) * 2 * 4);
+  const size_t nch = (size_t)cm_chunks(B);
+  size_t pb = nch * 128 * 2 * 4;
+  pb = std::max(pb, nch * ((size_t)32 * F * 3 + 32) * 4);
+  pb = std::max(pb, nch * ((size_t)128 * 64 * 3 + 128) * 4);
+  p.partial = take(pb);
+  p.total = off;
+  return p;
+}
+
+struct St { float *mean, *var, *invstd; };
+St st1d(char* ws, const Train1dPlan& pl, int l) {
+  const int off[3] = {0, 32, 96}, C[3] = {32, 64, 128};
+  float* b = (float*)(ws + pl.stats) + 3 * off[l];
+  return {b, b + C[l], b + 2 * C[l]};
+}
+float* sums1d(char* ws, const Train1dPlan& pl, int l) {
+  const int off[3] = {0, 32, 96};
+  return (float*)(ws + pl.sums) + 2 * off[l];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dfa_cnn1d_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F) {
+  (void)ctx;
+  if (B < 1 || T < 1 || F < 1) return 0;
+  return plan_train1d(B, T, F).total;
+}
+
+int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                            int64_t stride_t, int64_t stride_f, float p_drop, uint64_t seed, uint64_t offset,
+                            float momentum, int update_running_stats, float* logits, void* workspace,
+                            size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn1dState& m = ctx->cnn1d;
+  if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_set_params has not been called");
+  if (!x || !logits || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, logits and workspace must be non-null");
+  if (x_dtype != DFA_DTYPE_F32) return fail(ctx, DFA_E_BAD_DTYPE, "cnn1d takes float32 input (got dtype %d)", x_dtype);
+  if (B < 1 || T < 1) return fail(ctx, DFA_E_BAD_SHAPE, "B and T must be >= 1 (got %d, %d)", B, T);
+  if (F != m.in_features) return fail(ctx, DFA_E_BAD_SHAPE, "feature dim %d does not match in_features=%d", F, m.in_features);
+  if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(ctx, DFA_E_BAD_SHAPE, "dropout p must be in [0, 1)");
+  const Train1dPlan pl = plan_train1d(B, T, F);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!m.train_packed) {
+    const size_t n = al((size_t)64 * 32 * 3 * 4) + al((size_t)128 * 64 * 3 * 4) + al(256 * 4);
+    DFA_HIP_CHECK(ctx, hipMalloc(&m.train_packed, n));
+    char* b = (char*)m.train_packed;
+    m.wt[0] = (float*)b;
+    m.wt[1] = (float*)(b + al((size_t)64 * 32 * 3 * 4));
+    m.zero_bias = (float*)(b + al((size_t)64 * 32 * 3 * 4) + al((size_t)128 * 64 * 3 * 4));
+  }
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[6], m.wt[0], m.zero_bias, 32, 64, s));
+  DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[12], m.wt[1], m.zero_bias, 64, 128, s));
+  DropCfg dc{};
+  dc.thresh = (p_drop > 0.f) ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
+  dc.scale = 1.0f / (1.0f - p_drop);
+  dc.seed = seed; dc.offset = offset;
+  m.train_drop = dc; m.train_B = B; m.train_T = T;
+  char* ws = (char*)workspace;
+  float* partial = (float*)(ws + pl.partial);
+  const int C[3] = {32, 64, 128}, Cin[3] = {F, 32, 64};
+  const int nch = cm_chunks(B);
+  for (int l = 0; l < 3; ++l) {
+    float* z = (float*)(ws + pl.z[l]);
+    const float* const* q = p + 6 * l;
+    if (l == 0) {
+      DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, q[0], q[1], z, B, F, 32, T, false, s, false));
+    } else {
+      const float* hin = (const float*)(ws + pl.h[l - 1]);
+      DFA_HIP_CHECK(ctx, launch_conv1d(hin, (int64_t)Cin[l] * T, T, 1, q[0], q[1], z, B, Cin[l], C[l], T, false, s, false));
+    }
+    St st = st1d(ws, pl, l);
+    DFA_HIP_CHECK(ctx, launch_cm_stats(z, partial, B, C[l], T, s));
+    DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nch, C[l], (double)B * T, st.mean, st.var, st.invstd,
+                                          update_running_stats ? (float*)q[4] : nullptr,
+                                          update_running_stats ? (float*)q[5] : nullptr, momentum, s));
+    if (l < 2) {
+      dc.layer = 1 + l;
+      DFA_HIP_CHECK(ctx, launch_cm_bn_relu_drop(z, st.mean, st.invstd, q[2], q[3], (float*)(ws + pl.h[l]), B, C[l], T, dc, s));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_cm_bn_relu_meant(z, st.mean, st.invstd, q[2], q[3], (float*)(ws + pl.pooled), B, 128, T, s));
+    }
+  }
+  DFA_HIP_CHECK(ctx, launch_linear((const float*)(ws + pl.pooled), p[18], p[19], logits, B, 128, s));
+  return DFA_OK;
+}
+
+int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                       int64_t stride_f, const float* dlogits, float* const* grads, int ngrads, void* workspace,
+                       size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn1dState& m = ctx->cnn1d;
+  if (!m.train_packed || m.train_B != B || m.train_T != T)
+    return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_backward must follow dfa_cnn1d_forward_train on the same batch");
+  if (!x || !dlogits || !grads || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, dlogits, grads and workspace must be non-null");
+  if (x_dtype != DFA_DTYPE_F32) return fail(ctx, DFA_E_BAD_DTYPE, "cnn1d takes float32 input");
+  if (ngrads != 14) return fail(ctx, DFA_E_BAD_SHAPE, "cnn1d has 14 parameters, got %d gradient pointers", ngrads);
+  for (int i = 0; i < 14; ++i)
+    if (!grads[i]) return fail(ctx, DFA_E_NULL_PTR, "gradient pointer %d is null", i);
+  const Train1dPlan pl = plan_train1d(B, T, F);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small");
+  char* ws = (char*)workspace;
+  float* partial = (float*)(ws + pl.partial);
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  DropCfg dc = m.train_drop;
+  const int C[3] = {32, 64, 128}, Cin[3] = {F, 32, 64};
+  float* dpooled = (float*)(ws + pl.dpooled);
+  DFA_HIP_CHECK(ctx, launch_linear_bwd(dlogits, p[18], (const float*)(ws + pl.pooled), dpooled, grads[12], grads[13], B, 128, s));
+  for (int l = 2; l >= 0; --l) {
+    const float* const* q = p + 6 * l;
+    St st = st1d(ws, pl, l);
+    float* sm = sums1d(ws, pl, l);
+    float* dz = (float*)(ws + pl.dz[l]);
+    const float* up = (l == 2) ? dpooled : (const float*)(ws + pl.dh[l]);
+    dc.layer = 1 + l;
+    DFA_HIP_CHECK(ctx, launch_cm_bn_bwd(l == 2 ? 0 : 1, (const float*)(ws + pl.z[l]), st.mean, st.invstd, q[2], q[3], up, partial, sm, dz,
+                                        B, C[l], T, dc, s));
+    hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], C[l]);
+    if (l == 0) {
+      DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)x, stride_b, stride_f, stride_t, partial, grads[0], grads[1], B, F, 32, T, s));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)(ws + pl.h[l - 1]), (int64_t)Cin[l] * T, T, 1, partial, grads[4 * l],
+                                             grads[4 * l + 1], B, Cin[l], C[l], T, s));
+      // data gradient: dh[l-1] = conv1d(dz; W'[Cin][Cout][3]) -- a Conv1d with Cout input channels, Cin output channels
+      DFA_HIP_CHECK(ctx, launch_conv1d(dz, (int64_t)C[l] * T, T, 1, m.wt[l - 1], m.zero_bias, (float*)(ws + pl.dh[l - 1]), B, C[l], Cin[l], T,
+                                       false, s, false));
+    }
+  }
+  DFA_HIP_CHECK(ctx, hipGetLastError());
+  return DFA_OK;
+}
+
+}  // extern "C"

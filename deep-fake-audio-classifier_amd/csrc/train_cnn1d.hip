@@ -1,0 +1,232 @@
+// train_cnn1d.hip -- training step of the 1-D CNN (src/train.py:71-76 over src/model_cnn1d.py:15-46): train-mode
+// forward (Conv1d -> BatchNorm1d(batch statistics) -> ReLU -> Dropout, x3; mean over T; Linear) and its backward.
+// Everything is channel-major [B][C][T] fp32 (the stored feature layout).  The whole network is 30.8 MFLOP/utt
+// (about 0.3 % of the 2-D CNN): these are LDS-tiled fp32 VALU kernels bound by reading the 231 KB input, not matrix-core
+// kernels.  Reductions are two-stage with a fixed order (deterministic).
+#include "dfa_internal.h"
+#include "rng.h"
+
+namespace dfa {
+
+// ---- per-channel sum / sum of squares of z[B][C][T]: one block per (channel, batch chunk) -> partial[chunk][C][2]
+__global__ __launch_bounds__(256) void cm_stats_kernel(const float* __restrict__ z, float* __restrict__ partial, int B,
+                                                       int C, int T, int bchunk) {
+  __shared__ float r1[256], r2[256];
+  const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+  const int b0 = ch * bchunk, b1 = min(B, b0 + bchunk);
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float* row = z + ((size_t)b * C + c) * T;
+    for (int t = tid; t < T; t += 256) { const float v = row[t]; s1 += v; s2 = fmaf(v, v, s2); }
+  }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { r1[tid] += r1[tid + off]; r2[tid] += r2[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { partial[((size_t)ch * C + c) * 2] = r1[0]; partial[((size_t)ch * C + c) * 2 + 1] = r2[0]; }
+}
+
+__device__ __forceinline__ float drop1(const DropCfg& dc, uint64_t idx) {
+  if (dc.thresh == 0) return 1.f;
+  float f[8];
+  drop_scale8(dc, idx & ~(uint64_t)7, f);
+  return f[idx & 7];
+}
+
+// ---- forward: h = dropout(relu(bn(z)))  (elementwise, [B][C][T])
+__global__ void cm_bn_relu_drop_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ h, int C, int T, size_t n,
+                                       DropCfg dc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)((i / T) % C);
+  const float y = fmaf((z[i] - mean[c]) * invstd[c], gamma[c], beta[c]);
+  h[i] = fmaxf(y, 0.f) * drop1(dc, i);
+}
+
+// ---- forward: pooled[b][c] = mean_t relu(bn(z[b][c][t]))   (one wave per (b, c) row)
+__global__ __launch_bounds__(256) void cm_bn_relu_meant_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ pooled,
+                                                               int C, int T, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int c = row % C;
+  const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+  float s = 0.f;
+  for (int t = lane; t < T; t += 64) s += fmaxf(fmaf(z[(size_t)row * T + t], sc, sh), 0.f);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) pooled[row] = s / (float)T;
+}
+
+// ---- BatchNorm1d backward, channel-major.  Upstream gradient of the BN output after the ReLU mask:
+//   SRC 0 (mean over T then Linear): dy = (y > 0) * dpooled[b][c] / T;   SRC 1 (dropout): dy = (y > 0) * dropscale * dh[b][c][t]
+template <int SRC>
+__global__ __launch_bounds__(256) void cm_bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ up, float* __restrict__ partial,
+                                                               int B, int C, int T, int bchunk, DropCfg dc) {
+  __shared__ float r1[256], r2[256];
+  const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+  const int b0 = ch * bchunk, b1 = min(B, b0 + bchunk);
+  const float mu = mean[c], is = invstd[c], gm = gamma[c], bt = beta[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const size_t base = ((size_t)b * C + c) * T;
+    for (int t = tid; t < T; t += 256) {
+      const float xh = (z[base + t] - mu) * is;
+      float g = (SRC == 0) ? up[(size_t)b * C + c] / (float)T : up[base + t] * drop1(dc, base + t);
+      const float dy = (fmaf(gm, xh, bt) > 0.f) ? g : 0.f;
+      s1 += dy;
+      s2 = fmaf(dy, xh, s2);
+    }
+  }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { r1[tid] += r1[tid + off]; r2[tid] += r2[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { partial[((size_t)ch * C + c) * 2] = r1[0]; partial[((size_t)ch * C + c) * 2 + 1] = r2[0]; }
+}
+
+template <int SRC>
+__global__ void cm_bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, const float* __restrict__ sums,
+                                       const float* __restrict__ up, float* __restrict__ dz, int C, int T, size_t n,
+                                       float inv_n, DropCfg dc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)((i / T) % C);
+  const size_t bc = i / T;
+  const float xh = (z[i] - mean[c]) * invstd[c];
+  const float g = (SRC == 0) ? up[bc] / (float)T : up[i] * drop1(dc, i);
+  const float dy = (fmaf(gamma[c], xh, beta[c]) > 0.f) ? g : 0.f;
+  dz[i] = gamma[c] * invstd[c] * (dy - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+}
+
+// ---- Conv1d weight gradient: dW[o][c][k] = sum_{b,t} dz[b][o][t] * h[b][c][t+k-1],  db[o] = sum dz.
+// Block = (16 output channels x 16 input channels) tile for one batch chunk; thread (o, c) keeps its 3 taps (+ bias
+// sum) in registers and walks time through LDS slabs of 64 frames.  partial[chunk][Cout][Cin][3] (+ [Cout] for db).
+constexpr int W1D_TT = 64;
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ h,
+                                                           int64_t hsb, int64_t hsc, int64_t hst,
+                                                           float* __restrict__ partial, int B, int Cin, int Cout, int T,
+                                                           int bchunk) {
+  __shared__ float dzs[16][W1D_TT];
+  __shared__ float hs[16][W1D_TT + 2];
+  const int tid = threadIdx.x, ol = tid >> 4, cl = tid & 15;
+  const int o0 = blockIdx.x * 16, c0 = blockIdx.y * 16, ch = blockIdx.z;
+  const int b0 = ch * bchunk, b1 = min(B, b0 + bchunk);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    for (int t0 = 0; t0 < T; t0 += W1D_TT) {
+      __syncthreads();
+      for (int e = tid; e < 16 * W1D_TT; e += 256) {
+        const int oo = e / W1D_TT, tt = e - oo * W1D_TT;
+        dzs[oo][tt] = (t0 + tt < T) ? dz[((size_t)b * Cout + o0 + oo) * T + t0 + tt] : 0.f;
+      }
+      for (int e = tid; e < 16 * (W1D_TT + 2); e += 256) {
+        const int cc = e / (W1D_TT + 2), tt = e - cc * (W1D_TT + 2);
+        const int t = t0 - 1 + tt, ci = c0 + cc;
+        hs[cc][tt] = (ci < Cin && t >= 0 && t < T) ? h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)t * hst] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int tt = 0; tt < W1D_TT; ++tt) {
+        const float d = dzs[ol][tt];
+        a0 = fmaf(d, hs[cl][tt], a0);
+        a1 = fmaf(d, hs[cl][tt + 1], a1);
+        a2 = fmaf(d, hs[cl][tt + 2], a2);
+        ab += d;
+      }
+    }
+  }
+  const int o = o0 + ol, c = c0 + cl;
+  float* rec = partial + (size_t)ch * ((size_t)Cout * Cin * 3 + Cout);
+  if (c < Cin) {
+    rec[((size_t)o * Cin + c) * 3] = a0;
+    rec[((size_t)o * Cin + c) * 3 + 1] = a1;
+    rec[((size_t)o * Cin + c) * 3 + 2] = a2;
+  }
+  if (blockIdx.y == 0 && cl == 0) rec[(size_t)Cout * Cin * 3 + o] = ab;
+}
+
+// data-gradient weights of Conv1d: W'[c][o][k'] = W[o][c][2-k']  (a Conv1d with Cin' = Cout, Cout' = Cin)
+__global__ void conv1d_dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, float* __restrict__ zero_bias,
+                                         int cin, int cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cin) zero_bias[i] = 0.f;
+  if (i >= cin * cout * 3) return;
+  const int k = i % 3, o = (i / 3) % cout, c = i / (3 * cout);
+  wt[i] = w[((size_t)o * cin + c) * 3 + (2 - k)];
+}
+
+// ================================================================================================ launchers
+constexpr int kCmChunks = 16;
+int cm_chunks(int B) { return B < kCmChunks ? B : kCmChunks; }
+
+hipError_t launch_cm_stats(const float* z, float* partial, int B, int C, int T, hipStream_t s) {
+  const int nch = cm_chunks(B), bchunk = (B + nch - 1) / nch;
+  hipLaunchKernelGGL(cm_stats_kernel, dim3(C, nch), dim3(256), 0, s, z, partial, B, C, T, bchunk);
+  return hipGetLastError();
+}
+hipError_t launch_cm_bn_relu_drop(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* h, int B, int C, int T, const DropCfg& dc, hipStream_t s) {
+  const size_t n = (size_t)B * C * T;
+  hipLaunchKernelGGL(cm_bn_relu_drop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, h, C, T, n, dc);
+  return hipGetLastError();
+}
+hipError_t launch_cm_bn_relu_meant(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* pooled, int B, int C, int T, hipStream_t s) {
+  const int rows = B * C;
+  hipLaunchKernelGGL(cm_bn_relu_meant_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, z, mean, invstd, gamma, beta, pooled, C, T, rows);
+  return hipGetLastError();
+}
+hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* up, float* partial, float* sums, float* dz, int B, int C,
+                            int T, const DropCfg& dc, hipStream_t s) {
+  const int nch = cm_chunks(B), bchunk = (B + nch - 1) / nch;
+  const size_t n = (size_t)B * C * T;
+  const float inv_n = (float)(1.0 / ((double)B * T));
+  if (src == 0)
+    hipLaunchKernelGGL(cm_bn_bwd_reduce_kernel<0>, dim3(C, nch), dim3(256), 0, s, z, mean, invstd, gamma, beta, up, partial, B, C, T, bchunk, dc);
+  else
+    hipLaunchKernelGGL(cm_bn_bwd_reduce_kernel<1>, dim3(C, nch), dim3(256), 0, s, z, mean, invstd, gamma, beta, up, partial, B, C, T, bchunk, dc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = launch_reduce_partials(partial, nch, C * 2, 1.0f, sums, s, nullptr);
+  if (e != hipSuccess) return e;
+  if (src == 0)
+    hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums, up, dz, C, T, n, inv_n, dc);
+  else
+    hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums, up, dz, C, T, n, inv_n, dc);
+  return hipGetLastError();
+}
+// partial: cm_chunks(B) * (Cout*Cin*3 + Cout) floats
+hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
+                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s) {
+  const int nch = cm_chunks(B), bchunk = (B + nch - 1) / nch;
+  hipLaunchKernelGGL(conv1d_wgrad_kernel, dim3(Cout / 16, (Cin + 15) / 16, nch), dim3(256), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int n = Cout * Cin * 3;
+  e = launch_reduce_partials_strided(partial, nch, n + Cout, 0, n, dw, s);
+  if (e != hipSuccess) return e;
+  return launch_reduce_partials_strided(partial, nch, n + Cout, n, Cout, db, s);
+}
+hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias, int cin, int cout, hipStream_t s) {
+  const int n = cin * cout * 3;
+  hipLaunchKernelGGL(conv1d_dgrad_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, wt, zero_bias, cin, cout);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

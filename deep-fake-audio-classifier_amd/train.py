@@ -107,7 +107,7 @@ def parse_args(argv=None):
     p.add_argument("--train-labels", default="data/train/labels.pkl")
     p.add_argument("--dev-features", default="data/dev/features.pkl")
     p.add_argument("--dev-labels", default="data/dev/labels.pkl")
-    p.add_argument("--model", default="cnn2d", choices=["cnn2d"])
+    p.add_argument("--model", default="cnn2d", choices=["cnn2d", "cnn1d"])
     p.add_argument("--batch-size", type=int, default=32)
     p.add_argument("--num-workers", type=int, default=2)
     p.add_argument("--epochs", type=int, default=10)
@@ -165,7 +165,13 @@ def main(argv=None):
     out_dir = os.path.join(args.checkpoint_dir, args.run_name) if args.run_name else args.checkpoint_dir
     best_path, last_path = os.path.join(out_dir, f"{args.model}_best.pt"), os.path.join(out_dir, f"{args.model}_last.pt")
 
-    model = CNN2D(in_features=args.in_features, dropout=args.dropout, precision=args.precision).to(device)
+    if args.model == "cnn1d":
+        from .model_cnn1d import CNN1D
+        if args.native or world > 1:
+            raise ValueError("--native / multi-GPU training is implemented for cnn2d; cnn1d trains through the autograd bridge")
+        model = CNN1D(in_features=args.in_features, dropout=args.dropout).to(device)
+    else:
+        model = CNN2D(in_features=args.in_features, dropout=args.dropout, precision=args.precision).to(device)
     weight_decay = args.weight_decay if args.weight_decay > 0 else 0.01      # AdamW default of src/train.py:321-325
     criterion = make_criterion(args.label_smoothing)
     augment_fn = build_augment_fn(args)

@@ -113,8 +113,65 @@ def cnn2d_train_forward(model, x, return_embedding=False):
     return Cnn2dTrainFunction.apply(x, model, *model.parameters())
 
 
+def _bind_cnn1d(model, ctx):
+    ts = model._abi_tensors()
+    for t in ts:
+        if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("CNN1D parameters must be contiguous float32 tensors on the GPU (model.to('cuda'))")
+    sig = (ctx.index, tuple(t.data_ptr() for t in ts))
+    if getattr(model, "_bound", None) != sig:
+        arr = _lib.ptr_array([t.detach() for t in ts])
+        _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_set_params(ctx.handle, arr, len(ts), model.in_features,
+                                                            model.base_channels))
+        model._bound = sig
+    model._prepared = None
+
+
+class Cnn1dTrainFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, x, model, *params):
+        if x.device.type != "cuda":
+            raise RuntimeError("dfa_amd.CNN1D runs on the GPU only: move the input with .to('cuda')")
+        if x.dtype != torch.float32:
+            raise ValueError(f"CNN1D takes float32 input, got {x.dtype}")
+        B, T, F = x.shape
+        ctx = _lib.Context.get(x.device)
+        with torch.cuda.device(ctx.index):
+            ctx.use_current_stream()
+            _bind_cnn1d(model, ctx)
+            nbytes = ctx.lib.dfa_cnn1d_train_workspace_bytes(ctx.handle, B, T, F)
+            ws = _train_ws(model, ctx, nbytes)
+            logits = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+            seed = getattr(model, "_drop_seed", None)
+            if seed is None:
+                seed = model._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            offset = _next_dropout_offset(model, B * 64 * T)
+            sb, st, sf = x.stride()
+            _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_forward_train(
+                ctx.handle, C.c_void_p(x.data_ptr()), _lib.DTYPE_F32, B, T, F, sb, st, sf, float(model.dropout), seed,
+                offset, 0.1, 1, C.c_void_p(logits.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel()))
+            for i in model._BN_IDX:
+                model.conv[i].num_batches_tracked += 1
+        fctx.model, fctx.x, fctx.ctx, fctx.ws = model, x, ctx, ws
+        return logits
+
+    @staticmethod
+    def backward(fctx, dlogits):
+        model, x, ctx, ws = fctx.model, fctx.x, fctx.ctx, fctx.ws
+        grads = [torch.empty_like(p) for p in model.parameters()]
+        B, T, F = x.shape
+        d = dlogits.contiguous().float()
+        with torch.cuda.device(ctx.index):
+            ctx.use_current_stream()
+            sb, st, sf = x.stride()
+            _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_backward(
+                ctx.handle, C.c_void_p(x.data_ptr()), _lib.DTYPE_F32, B, T, F, sb, st, sf, C.c_void_p(d.data_ptr()),
+                _lib.ptr_array(grads), len(grads), C.c_void_p(ws.data_ptr()), ws.numel()))
+        return (None, None, *grads)
+
+
 def cnn1d_train_forward(model, x):
-    raise NotImplementedError("CNN1D training on the HIP path is not built yet (DESIGN.md section 6); eval only")
+    return Cnn1dTrainFunction.apply(x, model, *model.parameters())
 
 
 def cae_train_forward(model, x):

@@ -131,6 +131,18 @@ int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
                       int64_t stride_t, int64_t stride_f, float* logits, void* workspace,
                       size_t workspace_bytes);
 
+/* CNN1D training step (fp32): same contract as the CNN2D pair above; dropout follows ReLU in blocks 1 and 2
+ * (src/model_cnn1d.py:20,26); grads[0..13] in parameters() order conv.0.*, conv.1.*, conv.4.*, conv.5.*, conv.8.*, conv.9.*,
+ * classifier.*. */
+size_t dfa_cnn1d_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F);
+int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                            int64_t stride_t, int64_t stride_f, float p_drop, uint64_t seed, uint64_t offset,
+                            float momentum, int update_running_stats, float* logits, void* workspace,
+                            size_t workspace_bytes);
+int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                       int64_t stride_t, int64_t stride_f, const float* dlogits, float* const* grads, int ngrads,
+                       void* workspace, size_t workspace_bytes);
+
 /* ---- ConvAutoencoder (replaces ConvAutoencoder.forward, src/model_cae.py:83-125, and the per-sample MSE of
  *      src/evaluation_cae.py:52-53 / src/hybrid_ensemble.py:55) ------------------------------------------------ */
 /* params: 44 device pointers (fp32) in state_dict order without num_batches_tracked:

@@ -176,3 +176,20 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(a, b), k
     with pytest.raises(FileNotFoundError):
         load_checkpoint(str(tmp_path / "missing.pt"))
+
+
+def test_flat_ingest_roundtrip(tmp_path):
+    from dfa_amd import ingest
+    fp, lp, feats, labels = _write_pickles(tmp_path, n=6)
+    meta = ingest.convert(fp, str(tmp_path / "flat"), lp, dtype="fp32")
+    ff = ingest.FlatFeatures(str(tmp_path / "flat"))
+    ds = AudioDeepfakeDataset(fp, lp)
+    stack, lab = ds.stacked()
+    assert len(ff) == 6 and ff.uttids == list(ds.uttids()) and meta["shape"] == [6, 180, 321]
+    assert torch.equal(ff.tensor(), stack) and torch.equal(ff.labels, lab)
+    ingest.convert(fp, str(tmp_path / "flat16"), None, dtype="bf16")
+    f16 = ingest.FlatFeatures(str(tmp_path / "flat16"))
+    assert f16.tensor().dtype == torch.bfloat16 and f16.labels is None
+    assert torch.equal(f16.tensor(), torch.stack(list(feats["features"])).to(torch.bfloat16))
+    parts = list(FlatBatcher(ff.tensor(), ff.labels, 4, device="cpu"))
+    assert [b[0].shape[0] for b in parts] == [4, 2]

@@ -213,3 +213,46 @@ def test_data_parallel_two_ranks_one_gpu(tmp_path):
         total += tr.flat_g
     scale = total.abs().max().item()
     assert (r0["g0"].cuda() - total).abs().max().item() <= 1e-5 * scale + 1e-7
+
+
+@pytest.mark.parametrize("tag,eps", [("ls0", 0.0), ("ls05", 0.05)])
+def test_cnn1d_train_step_matches_reference(golden, tag, eps):
+    """CNN1D training step (dropout 0) against the reference's autograd gradients and AdamW results."""
+    from dfa_amd.model_cnn1d import CNN1D
+    _, g = golden("cnn1d_train")
+    m = CNN1D(in_features=180, dropout=0.0)
+    m.load_state_dict({k[len("init.sd."):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("init.sd.")})
+    m = m.to("cuda").train()
+    x = torch.from_numpy(g[f"{tag}.x"]).to("cuda").transpose(1, 2)
+    y = torch.from_numpy(g[f"{tag}.y"]).to("cuda")
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    logits = m(x).squeeze(-1)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, _smooth(y, eps))
+    opt.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g[f"{tag}.logits"], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}.loss"], rtol=1e-5)
+    noise = ("conv.0.bias", "conv.4.bias", "conv.8.bias")        # zero-gradient biases in front of batch-stat BN
+    for name, p in m.named_parameters():
+        want, got = g[f"{tag}.grad.{name}"], p.grad.cpu().numpy()
+        if name in noise:
+            floor = 1e-4 * np.abs(g[f"{tag}.grad.{name.replace('bias', 'weight')}"]).max() + 1e-6
+            assert np.abs(got).max() < floor and np.abs(want).max() < floor, name
+            continue
+        scale = max(np.abs(want).max(), 1e-6)
+        np.testing.assert_allclose(got, want, atol=2e-4 * scale + 1e-7, rtol=2e-3, err_msg=name)
+    opt.step()
+    for k, v in m.state_dict().items():
+        want = g[f"{tag}.after1.{k}"]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(want)
+        elif k in noise:
+            assert np.abs(v.cpu().numpy() - g["init.sd." + k]).max() <= 1.02e-3 + 1e-6
+        elif k.endswith("running_mean"):
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=1.1e-3, rtol=2e-4, err_msg=k)
+        else:
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=2e-5, rtol=2e-4, err_msg=k)
+    # dropout > 0 runs and changes from call to call
+    m.dropout = 0.3
+    a, b = m(x), m(x)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
