@@ -16,9 +16,24 @@ hipError_t launch_train_fwd3(int prec, const ConvArgs& a, hipStream_t s) {
   return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, false, true, true>(a, s);
 }
 
-// a.wpack: bf16 -> one [64/32][9][128/16][64] image; fp32 -> two consecutive [64/32][9][64/8][64] images
+// a.wpack: two consecutive [64/32][9][64/KG][64] images (Cin halves 0-63, 64-127).  Cin = 128 in ONE launch needs
+// 288 weight VGPRs + the two-row epilogue and spills (1.44 ms measured for the bf16 form); two 64-channel launches
+// (raw fp32 partial sums, then accumulate + store) run spill-free.
 hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
-  if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 128, 2, 2, 2, 1, EPI_PLAIN, 1, false, true>(a, s);
+  if (prec == DFA_PREC_BF16) {
+    ConvArgs p1 = a;
+    p1.in_pix_bytes = 128 * 2;
+    p1.in_ch_off_bytes = 0;
+    p1.raw_out = raw_tmp;
+    hipError_t e = launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_RAW, 1, false, true>(p1, s);
+    if (e != hipSuccess) return e;
+    ConvArgs p2 = a;
+    p2.in_pix_bytes = 128 * 2;
+    p2.in_ch_off_bytes = 64 * 2;
+    p2.acc_in = raw_tmp;
+    p2.wpack = a.wpack + (size_t)(64 / 32) * 9 * 4 * 64;
+    return launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_PLAIN, 2, true, false>(p2, s);
+  }
   ConvArgs p1 = a;
   p1.in_pix_bytes = 128 * 4;
   p1.in_ch_off_bytes = 0;

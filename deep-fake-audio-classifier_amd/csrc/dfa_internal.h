@@ -192,7 +192,7 @@ hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, 
 hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
                                 const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
-                             int B, int K, hipStream_t s);
+                             int B, int K, hipStream_t s, int tc = 0, int tw = 0);
 int bn_bwd_blocks(int B, int H, int W, int* pix_per_block);
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,

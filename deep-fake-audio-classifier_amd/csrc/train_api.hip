@@ -58,7 +58,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   p.da2 = take((size_t)B * p.H2 * F * 64 * es);
   p.dz2 = take((size_t)B * p.H1 * F * 64 * es);
   p.da1 = take((size_t)B * p.H1 * F * 32 * es);
-  p.raw = take(prec == DFA_PREC_F32 ? (size_t)B * p.H2 * F * 64 * 4 : 0);
+  p.raw = take((size_t)B * p.H2 * F * 64 * 4);
   p.stats = take((32 + 64 + 128) * 3 * 4);          // mean | var | invstd per layer
   p.sums = take((32 + 64 + 128) * 2 * 4 + 320 * 4);  // (S1,S2) per layer + conv1 wgrad record
   const int nstrips = (F + 31) / 32;
@@ -133,11 +133,10 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], nullptr, nullptr, nullptr, nullptr, 32, 0, 32, 64, prec, m.t2.wpack, m.t2.bias, s, 0));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 0, 64, 128, prec, m.t3.wpack, m.t3.bias, s, 0));
   DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[6], 32, 64, 0, 64, prec, m.d2.wpack, m.d2.bias, s));
-  if (prec == DFA_PREC_BF16) {
-    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 0, 128, prec, m.d3.wpack, m.d3.bias, s));
-  } else {
+  {  // two Cin halves (see launch_train_dgrad3)
+    const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 0, 64, prec, m.d3.wpack, m.d3.bias, s));
-    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64, 64, prec, m.d3.wpack + (size_t)(64 / 32) * 9 * 8 * 64, m.d3.bias, s));
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64, 64, prec, m.d3.wpack + (size_t)(64 / 32) * 9 * nkg * 64, m.d3.bias, s));
   }
   char* ws = (char*)workspace;
   float* partial = (float*)(ws + pl.partial);
@@ -211,7 +210,7 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   float* c1rec = (float*)(ws + pl.sums) + 2 * (32 + 64 + 128);
   float* demb = (float*)(ws + pl.demb);
   // classifier
-  DFA_HIP_CHECK(ctx, launch_linear_bwd(dlogits, p[18], (const float*)(ws + pl.emb), demb, grads[12], grads[13], B, 128 * F, s));
+  DFA_HIP_CHECK(ctx, launch_linear_bwd(dlogits, p[18], (const float*)(ws + pl.emb), demb, grads[12], grads[13], B, 128 * F, s, 128, F));
   // block 3: BN backward (upstream = mean_T then Linear), weight gradient, data gradient
   DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_MEANT, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], demb, nullptr, partial, sm3, ws + pl.dz3,
                                    B, pl.H2, F, 128, dc, s));

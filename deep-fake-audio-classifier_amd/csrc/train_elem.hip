@@ -165,9 +165,11 @@ __global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict_
 }
 
 // ---- backward of Linear(K,1): demb[b][j] = dlogit[b]*w[j];  dw[j] = sum_b dlogit[b]*emb[b][j];  db = sum_b dlogit[b]
+// tc > 0: demb is written TRANSPOSED per utterance, j = c*tw + f  ->  demb[b][f][c] (tc channels, tw columns), the
+// channels-last order the BatchNorm backward of block 3 reads 8 channels at a time.
 __global__ void linear_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
                                   const float* __restrict__ emb, float* __restrict__ demb, float* __restrict__ dw,
-                                  float* __restrict__ db, int B, int K) {
+                                  float* __restrict__ db, int B, int K, int tc, int tw) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0) {
     float s = 0.f;
@@ -176,10 +178,11 @@ __global__ void linear_bwd_kernel(const float* __restrict__ dlogits, const float
   }
   if (j >= K) return;
   const float wj = w[j];
+  const int jt = (tc > 0) ? (j % tw) * tc + j / tw : j;
   float s = 0.f;
   for (int b = 0; b < B; ++b) {
     const float d = dlogits[b];
-    demb[(size_t)b * K + j] = d * wj;
+    demb[(size_t)b * K + jt] = d * wj;
     s = fmaf(d, emb[(size_t)b * K + j], s);
   }
   dw[j] = s;
@@ -195,8 +198,10 @@ template <typename T, int SRC>
 __device__ __forceinline__ void upstream8(const float* demb, const T* da, const DropCfg& dc, int b, int t, int f, int cg,
                                           int H, int W, int C, float inv_h, float* g) {
   if (SRC == SRC_MEANT) {
+    float d[8];
+    ld8<float>(demb + ((size_t)b * W + f) * C + cg * 8, d);   // demb is [B][W][C] (linear_bwd_kernel with tc > 0)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = demb[((size_t)b * C + cg * 8 + j) * W + f] * inv_h;
+    for (int j = 0; j < 8; ++j) g[j] = d[j] * inv_h;
   } else {
     const int Ho = H >> 1, to = t >> 1;
     if (to >= Ho) {
@@ -380,8 +385,8 @@ hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, cons
 }
 
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
-                             int B, int K, hipStream_t s) {
-  hipLaunchKernelGGL(linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, s, dlogits, w, emb, demb, dw, db, B, K);
+                             int B, int K, hipStream_t s, int tc, int tw) {
+  hipLaunchKernelGGL(linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, s, dlogits, w, emb, demb, dw, db, B, K, tc, tw);
   return hipGetLastError();
 }
 
