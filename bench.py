@@ -78,8 +78,16 @@ def timed_steps(torch, dist, model, x, steps, warmup, world):
     ctx = _lib.Context.get(x.device)
     for _ in range(warmup):
         model(x)
+    # per-kernel breakdown from an untimed pass; inside the timed region only the dominant kernel (slot 2) is bracketed
     ctx.timing_reset()
     ctx.timing(True)
+    for _ in range(3):
+        model(x)
+    ctx.timing(False)
+    torch.cuda.synchronize()
+    breakdown = [ctx.timing_read(s) for s in range(4)]
+    ctx.timing_reset()
+    ctx.timing(1 << 2)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -91,7 +99,8 @@ def timed_steps(torch, dist, model, x, steps, warmup, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     ctx.timing(False)
-    slots = [ctx.timing_read(s) for s in range(4)]
+    slots = list(breakdown)
+    slots[2] = ctx.timing_read(2)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -169,11 +178,18 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in dfa_amd)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DFA_BENCH_SHARE_GPU=1 is a rehearsal switch for 1-GPU boxes: every rank uses device 0 and the (timing-only)
+    # collectives run over gloo, so the N > 1 code path can be exercised without N GPUs.  Never set for real runs.
+    share = os.environ.get("DFA_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)

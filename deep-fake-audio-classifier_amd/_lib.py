@@ -136,8 +136,9 @@ class Context:
         check(self.handle, self.lib.dfa_ctx_set_option(self.handle, name.encode(), int(value)))
 
     # ---- timing -----------------------------------------------------------------------------------------------
-    def timing(self, enable: bool):
-        check(self.handle, self.lib.dfa_ctx_timing_enable(self.handle, int(bool(enable))))
+    def timing(self, enable):
+        """False/0 = off, True/1 = every slot, other int = bit mask of slots (1 << slot)."""
+        check(self.handle, self.lib.dfa_ctx_timing_enable(self.handle, int(enable)))
 
     def timing_reset(self):
         check(self.handle, self.lib.dfa_ctx_timing_reset(self.handle))

@@ -154,7 +154,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
 
 int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable) {
   if (!ctx) return DFA_E_NULL_PTR;
-  ctx->timing = enable != 0;
+  ctx->timing = (enable == 1) ? 0xffffffffu : (unsigned)enable;   // 1 = all slots, otherwise a bit mask of slots
   return DFA_OK;
 }
 

@@ -84,7 +84,7 @@ struct dfa_ctx {
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
   dfa::CaeState cae;
-  bool timing = false;
+  unsigned timing = 0;         // bit s set: record HIP events around the launches of timing slot s
   dfa::SlotTimer slots[dfa::kMaxSlots];
 };
 
@@ -114,7 +114,7 @@ struct ScopedSlot {
   int slot;
   int idx;
   ScopedSlot(dfa_ctx* c, int s) : ctx(c), slot(s), idx(-1) {
-    if (!ctx->timing) return;
+    if (!((ctx->timing >> slot) & 1u)) return;
     SlotTimer& t = ctx->slots[slot];
     if (t.used >= kEventsPerSlot) return;
     if ((int)t.start.size() <= t.used) {

@@ -170,6 +170,7 @@ const char* dfa_dominant_kernel(int model, int precision);
 /* ---- per-kernel timing (HIP events recorded on the context's stream around every launch) -------------
  * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear;
  * CNN1D: 4, 5, 6 = conv blocks, 7 = linear;  CAE: 8 = enc1, 9-11 = enc2-4 (MFMA), 12-14 = dec1-3 (MFMA), 15 = dec4+MSE.
+ * enable: 0 = off, 1 = all slots, any other value = bit mask of slots (e.g. 1<<2 = block 3 only).
  * Enable, run forwards, then read (read synchronises on the recorded events; call it outside timed regions).
  * At most 256 launches per slot are recorded between resets. */
 int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable);
