@@ -60,6 +60,12 @@ SYMBOLS = [
     ("dfa_cae_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t]),
+    ("dfa_cae_train_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("dfa_cae_forward_train", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                        C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t]),
+    ("dfa_cae_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                   C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
     ("dfa_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("dfa_dominant_kernel", C.c_char_p, [C.c_int, C.c_int]),
     ("dfa_ctx_timing_enable", C.c_int, [C.c_void_p, C.c_int]),

@@ -129,6 +129,7 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   if (ctx->cnn1d.packed) (void)hipFree(ctx->cnn1d.packed);
   if (ctx->cnn1d.train_packed) (void)hipFree(ctx->cnn1d.train_packed);
   if (ctx->cae.packed) (void)hipFree(ctx->cae.packed);
+  if (ctx->cae.train_packed) (void)hipFree(ctx->cae.train_packed);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   for (auto& t : ctx->slots) {
     for (auto e : t.start) (void)hipEventDestroy(e);

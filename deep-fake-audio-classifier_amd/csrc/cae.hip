@@ -77,11 +77,12 @@ __global__ __launch_bounds__(256) void cae_enc1_kernel(const TX* __restrict__ x,
 }
 
 template <typename T>
-__global__ void cae_opad_col_kernel(T* __restrict__ out, const float* __restrict__ bias, int rows, int Wo, int C) {
+__global__ void cae_opad_col_kernel(T* __restrict__ out, const float* __restrict__ bias, int rows, int Wo, int C,
+                                    int no_relu) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over rows*C
   if (i >= rows * C) return;
   const int row = i / C, c = i - row * C;
-  out[((size_t)row * Wo + (Wo - 1)) * C + c] = cvt_out<T>(fmaxf(bias[c], 0.f));
+  out[((size_t)row * Wo + (Wo - 1)) * C + c] = cvt_out<T>(no_relu ? bias[c] : fmaxf(bias[c], 0.f));
 }
 
 template <typename T>
@@ -201,12 +202,13 @@ hipError_t launch_cae_enc1(const void* x, int x_dtype, int64_t sb, int64_t st, i
   return hipGetLastError();
 }
 
-hipError_t launch_cae_opad_col(void* out, const float* bias, int prec, int rows, int Wo, int C, hipStream_t s) {
+hipError_t launch_cae_opad_col(void* out, const float* bias, int prec, int rows, int Wo, int C, hipStream_t s,
+                               int no_relu) {
   const int n = rows * C;
   if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(cae_opad_col_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (bf16_t*)out, bias, rows, Wo, C);
+    hipLaunchKernelGGL(cae_opad_col_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (bf16_t*)out, bias, rows, Wo, C, no_relu);
   else
-    hipLaunchKernelGGL(cae_opad_col_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, (float*)out, bias, rows, Wo, C);
+    hipLaunchKernelGGL(cae_opad_col_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, (float*)out, bias, rows, Wo, C, no_relu);
   return hipGetLastError();
 }
 

@@ -1,0 +1,313 @@
+// cae_train_api.hip -- C ABI of the ConvAutoencoder training step (replaces, for src/train_cae.py:58-82, torch autograd
+// over src/model_cae.py:32-125):  dfa_cae_forward_train (BatchNorm with batch statistics, running-stat update, keeps
+// what backward needs in the workspace) and dfa_cae_backward (gradients of the 30 parameters from d(loss)/d(recon)).
+#include "dfa_internal.h"
+#include "convt2x2_mfma.h"
+
+using namespace dfa;
+
+namespace dfa {
+hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_cae_dgrad4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_train_dgrad2(int prec, const ConvArgs& a, hipStream_t s);
+__global__ void split_sums_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C);
+__global__ void split_c1_kernel(const float* __restrict__ rec, float* __restrict__ dw, float* __restrict__ db);
+enum { C1M_STATS = 0, C1M_BWD_REDUCE = 1, C1M_WGRAD = 2 };
+enum { SRC_MEANT = 0, SRC_POOL = 1, SRC_DIRECT = 2, SRC_POOL22 = 3 };
+}  // namespace dfa
+
+namespace {
+
+inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+constexpr int kWgradWGs = 256, kGemmSplit = 64;
+const int kEC[4] = {32, 64, 128, 256};     // encoder block output channels
+const int kDC[3] = {128, 64, 32};          // decoder block 1-3 output channels
+const int kDCin[3] = {256, 128, 64};
+
+struct CaeTrainPlan {
+  int H[5], W[5], Hd[4], Wd[4];
+  bool ok;
+  size_t e[4], z[4], zd[3], d[3], dd[3], dzd[3], de[4], dz[4], zp, xf, raw, stats, sums, wq, dwq, rec, partial, total;
+};
+
+CaeTrainPlan plan_cae_train(int B, int T, int F, int prec) {
+  CaeTrainPlan p;
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  p.H[0] = T; p.W[0] = F;
+  for (int l = 1; l <= 4; ++l) { p.H[l] = p.H[l - 1] / 2; p.W[l] = p.W[l - 1] / 2; }
+  p.Hd[0] = 2 * p.H[4]; p.Wd[0] = 2 * p.W[4];
+  p.Hd[1] = 2 * p.Hd[0]; p.Wd[1] = 2 * p.Wd[0] + 1;
+  p.Hd[2] = 2 * p.Hd[1]; p.Wd[2] = 2 * p.Wd[1];
+  p.Hd[3] = 2 * p.Hd[2]; p.Wd[3] = 2 * p.Wd[2];
+  p.ok = (p.H[4] >= 1 && p.W[4] >= 1 && p.Wd[3] == F);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
+  for (int l = 0; l < 4; ++l) p.e[l] = take((size_t)B * p.H[l + 1] * p.W[l + 1] * kEC[l] * es);
+  p.z[0] = 0;  // block 1's pre-BN output is recomputed, never stored
+  for (int l = 1; l < 4; ++l) p.z[l] = take((size_t)B * p.H[l] * p.W[l] * kEC[l] * es);
+  for (int l = 0; l < 3; ++l) p.zd[l] = take((size_t)B * p.Hd[l] * p.Wd[l] * kDC[l] * es);
+  for (int l = 0; l < 3; ++l) p.d[l] = take((size_t)B * p.Hd[l] * p.Wd[l] * kDC[l] * es);
+  for (int l = 0; l < 3; ++l) p.dd[l] = take((size_t)B * p.Hd[l] * p.Wd[l] * kDC[l] * es);
+  for (int l = 0; l < 3; ++l) p.dzd[l] = take((size_t)B * p.Hd[l] * p.Wd[l] * kDC[l] * es);
+  for (int l = 0; l < 4; ++l) p.de[l] = take((size_t)B * p.H[l + 1] * p.W[l + 1] * kEC[l] * es);
+  p.dz[0] = 0;
+  for (int l = 1; l < 4; ++l) p.dz[l] = take((size_t)B * p.H[l] * p.W[l] * kEC[l] * es);
+  size_t zp = 0, xf = 0;
+  for (int l = 0; l < 3; ++l) {
+    const size_t P = (size_t)B * (p.Hd[l] / 2) * (l == 1 ? (p.Wd[l] - 1) / 2 : p.Wd[l] / 2);
+    zp = std::max(zp, P * 4 * kDC[l] * es);
+    xf = std::max(xf, P * kDCin[l] * 4);
+  }
+  p.zp = take(zp);
+  p.xf = take(xf);
+  size_t raw = (size_t)B * p.H[3] * p.W[3] * 256 * 4;                    // enc4 forward split
+  raw = std::max(raw, (size_t)B * p.H[2] * p.W[2] * 64 * 4);             // dgrad3
+  p.raw = take(raw);
+  p.stats = take(704 * 3 * 4);
+  p.sums = take(704 * 2 * 4 + 1024 * 4);
+  p.wq = take((size_t)256 * 512 * 4);
+  p.dwq = take((size_t)256 * 512 * 4);
+  p.rec = take(1024 * 4);
+  size_t pb = (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 128) * 4;
+  pb = std::max(pb, (size_t)kGemmSplit * 256 * 512 * 4);
+  pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 320 * 4);
+  int ppb;
+  pb = std::max(pb, (size_t)cl_stats_blocks((size_t)B * T * F, &ppb) * 256 * 2 * 4);
+  pb = std::max(pb, (size_t)cae_dec4_bwd_blocks() * 132 * 4);
+  p.partial = take(pb);
+  p.total = off;
+  return p;
+}
+
+// BN layer order in the stats / sums blocks: enc1..enc4 (32, 64, 128, 256), dec1..dec3 (128, 64, 32)
+const int kBnOff[7] = {0, 32, 96, 224, 480, 608, 672};
+struct St { float *mean, *var, *invstd; };
+St stat_of(char* ws, const CaeTrainPlan& pl, int layer, int C) {
+  float* b = (float*)(ws + pl.stats) + 3 * kBnOff[layer];
+  return {b, b + C, b + 2 * C};
+}
+float* sums_of(char* ws, const CaeTrainPlan& pl, int layer) { return (float*)(ws + pl.sums) + 2 * kBnOff[layer]; }
+
+int finalize_stats(dfa_ctx* ctx, int prec, const void* z, size_t npix, int C, const St& st, float* partial, float* rm,
+                   float* rv, float momentum) {
+  int ppb;
+  const int nblk = cl_stats_blocks(npix, &ppb);
+  DFA_HIP_CHECK(ctx, launch_cl_stats(prec, z, partial, npix, C, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nblk, C, (double)npix, st.mean, st.var, st.invstd, rm, rv, momentum, ctx->stream));
+  return DFA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dfa_cae_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F, int precision) {
+  (void)ctx;
+  if (B < 1 || T < 16 || F < 16) return 0;
+  const CaeTrainPlan pl = plan_cae_train(B, T, F, precision);
+  return pl.ok ? pl.total : 0;
+}
+
+int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                          int64_t stride_f, int precision, float momentum, int update_running_stats, float* recon,
+                          float* latent, float* mse, void* workspace, size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  CaeState& m = ctx->cae;
+  if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_set_params has not been called");
+  if (!x || !recon || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, recon and workspace must be non-null");
+  if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
+  if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
+  if (B < 1 || T < 16) return fail(ctx, DFA_E_BAD_SHAPE, "need B >= 1 and T >= 16 (got %d, %d)", B, T);
+  const CaeTrainPlan pl = plan_cae_train(B, T, F, precision);
+  if (!pl.ok) return fail(ctx, DFA_E_BAD_SHAPE, "F=%d: decoder would rebuild %d columns (needs F = 16*(F/16)+4)", F, pl.Wd[3]);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int prec = precision;
+  if (!m.train_packed) {  // raw conv images enc2-4 (+ their dgrad images), raw convT images, conv1 fold target, biases
+    size_t off = al((288 + 32) * 4);
+    size_t eb[3], db[3], ew[3], dgw[3], dw[3], dgb;
+    for (int l = 0; l < 3; ++l) { eb[l] = off; off = al(off + kEC[l + 1] * 4); }
+    for (int l = 0; l < 3; ++l) { db[l] = off; off = al(off + kDC[l] * 4); }
+    dgb = off; off = al(off + 256 * 4);
+    for (int l = 0; l < 3; ++l) { ew[l] = off; off = al(off + (size_t)kEC[l + 1] * kEC[l] * 9 * 4); }
+    for (int l = 0; l < 3; ++l) { dgw[l] = off; off = al(off + (size_t)kEC[l + 1] * kEC[l] * 9 * 4); }
+    for (int l = 0; l < 3; ++l) { dw[l] = off; off = al(off + (size_t)kDC[l] * kDCin[l] * 4 * 4); }
+    DFA_HIP_CHECK(ctx, hipMalloc(&m.train_packed, off));
+    char* b = (char*)m.train_packed;
+    m.tw1 = (float*)b; m.tb1 = m.tw1 + 288;
+    for (int l = 0; l < 3; ++l) {
+      m.tenc[l].bias = (float*)(b + eb[l]); m.tenc[l].wpack = (uint4*)(b + ew[l]);
+      m.tdg[l].bias = (float*)(b + dgb); m.tdg[l].wpack = (uint4*)(b + dgw[l]);
+      m.tdec[l].bias = (float*)(b + db[l]); m.tdec[l].wpack = (uint4*)(b + dw[l]);
+    }
+  }
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  char* ws = (char*)workspace;
+  float* partial = (float*)(ws + pl.partial);
+  const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
+  // ---- weight images (weights move every step)
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], nullptr, nullptr, nullptr, nullptr, 32, 0, 32, 64, prec, m.tenc[0].wpack, m.tenc[0].bias, s, 0));
+  DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 0, 64, 128, prec, m.tenc[1].wpack, m.tenc[1].bias, s, 0));
+  for (int hlf = 0; hlf < 2; ++hlf)
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[18], p[19], nullptr, nullptr, nullptr, nullptr, 128, 64 * hlf, 64, 256, prec,
+                                                m.tenc[2].wpack + (size_t)hlf * (256 / 32) * 9 * nkg * 64, m.tenc[2].bias, s, 0));
+  DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[6], 32, 64, 0, 64, prec, m.tdg[0].wpack, m.tdg[0].bias, s));
+  for (int hlf = 0; hlf < 2; ++hlf)
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64 * hlf, 64, prec, m.tdg[1].wpack + (size_t)hlf * (64 / 32) * 9 * nkg * 64, m.tdg[1].bias, s));
+  for (int c = 0; c < 4; ++c)
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[18], 128, 256, 64 * c, 64, prec, m.tdg[2].wpack + (size_t)c * (128 / 32) * 9 * nkg * 64, m.tdg[2].bias, s));
+  for (int l = 0; l < 3; ++l) {
+    const float* const* q = p + 24 + 6 * l;
+    DFA_HIP_CHECK(ctx, launch_fold_pack_convt2x2(q[0], q[1], nullptr, nullptr, nullptr, nullptr, kDCin[l], kDC[l], prec, m.tdec[l].wpack, m.tdec[l].bias, s, 0));
+  }
+  m.train_prec = prec; m.train_B = B; m.train_T = T;
+  auto rmv = [&](int pi) { return update_running_stats ? (float*)p[pi] : nullptr; };
+  DropCfg nodrop{};
+  // ---- encoder block 1 (pre-BN output recomputed from x: statistics pass, fold, fused eval kernel)
+  {
+    St st = stat_of(ws, pl, 0, 32);
+    DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, nullptr, prec, partial, B, T, F, nodrop, s));
+    DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, st.mean, st.var, st.invstd, rmv(4), rmv(5), momentum, s));
+    DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], st.mean, st.var, m.tw1, m.tb1, 32, s));
+    DFA_HIP_CHECK(ctx, launch_cae_enc1(x, x_dtype, stride_b, stride_t, stride_f, nullptr, nullptr, m.tw1, m.tb1, ws + pl.e[0], prec, B, T, F, s));
+  }
+  // ---- encoder blocks 2-4
+  for (int l = 1; l < 4; ++l) {
+    ConvArgs a{};
+    a.in = ws + pl.e[l - 1]; a.wpack = m.tenc[l - 1].wpack; a.bias = m.tenc[l - 1].bias; a.out = ws + pl.z[l];
+    a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l]; a.relu = 0; a.zero_page = ctx->zero_page;
+    DFA_HIP_CHECK(ctx, launch_cae_train_fwd(prec, kEC[l - 1], a, (float*)(ws + pl.raw), s));
+    St st = stat_of(ws, pl, l, kEC[l]);
+    int rc = finalize_stats(ctx, prec, ws + pl.z[l], (size_t)B * pl.H[l] * pl.W[l], kEC[l], st, partial, rmv(6 * l + 4), rmv(6 * l + 5), momentum);
+    if (rc != DFA_OK) return rc;
+    DFA_HIP_CHECK(ctx, launch_bn_relu_pool(prec, 2, ws + pl.z[l], st.mean, st.invstd, p[6 * l + 2], p[6 * l + 3], ws + pl.e[l], B, pl.H[l], pl.W[l], kEC[l], s));
+  }
+  if (latent) DFA_HIP_CHECK(ctx, launch_cae_latent_export(ws + pl.e[3], prec, latent, B, pl.H[4] * pl.W[4], 256, s));
+  // ---- decoder blocks 1-3: raw ConvTranspose2d -> statistics -> BN + ReLU
+  for (int l = 0; l < 3; ++l) {
+    const float* const* q = p + 24 + 6 * l;
+    ConvTArgs a{};
+    a.in = (l == 0) ? ws + pl.e[3] : ws + pl.d[l - 1];
+    a.wpack = m.tdec[l].wpack; a.bias = m.tdec[l].bias; a.out = ws + pl.zd[l];
+    a.B = B; a.H = pl.Hd[l] / 2; a.W = (l == 1) ? (pl.Wd[l] - 1) / 2 : pl.Wd[l] / 2;
+    a.COUT = kDC[l]; a.opad_w = (l == 1) ? 1 : 0; a.no_relu = 1;
+    DFA_HIP_CHECK(ctx, launch_cae_dec(prec, kDCin[l], a, s));
+    if (l == 1) DFA_HIP_CHECK(ctx, launch_cae_opad_col(ws + pl.zd[1], m.tdec[1].bias, prec, B * pl.Hd[1], pl.Wd[1], 64, s, 1));
+    St st = stat_of(ws, pl, 4 + l, kDC[l]);
+    int rc = finalize_stats(ctx, prec, ws + pl.zd[l], (size_t)B * pl.Hd[l] * pl.Wd[l], kDC[l], st, partial, rmv(24 + 6 * l + 4), rmv(24 + 6 * l + 5), momentum);
+    if (rc != DFA_OK) return rc;
+    DFA_HIP_CHECK(ctx, launch_bn_relu_pool(prec, 1, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], ws + pl.d[l], B, pl.Hd[l], pl.Wd[l], kDC[l], s));
+  }
+  // ---- decoder block 4 + zero time padding (+ per-sample MSE)
+  DFA_HIP_CHECK(ctx, launch_cae_dec4_mse(ws + pl.d[2], prec, p[42], p[43], x, x_dtype, stride_b, stride_t, stride_f, nullptr, nullptr, recon,
+                                         partial, mse, B, pl.Hd[2], pl.Wd[2], T, F, s));
+  return DFA_OK;
+}
+
+int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                     int64_t stride_f, const float* drecon, float* const* grads, int ngrads, void* workspace,
+                     size_t workspace_bytes) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  CaeState& m = ctx->cae;
+  if (!m.train_packed || m.train_B != B || m.train_T != T)
+    return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_backward must follow dfa_cae_forward_train on the same batch");
+  if (!x || !drecon || !grads || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, drecon, grads and workspace must be non-null");
+  if (ngrads != 30) return fail(ctx, DFA_E_BAD_SHAPE, "the auto-encoder has 30 parameters, got %d gradient pointers", ngrads);
+  for (int i = 0; i < 30; ++i)
+    if (!grads[i]) return fail(ctx, DFA_E_NULL_PTR, "gradient pointer %d is null", i);
+  const int prec = m.train_prec;
+  const CaeTrainPlan pl = plan_cae_train(B, T, F, prec);
+  if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small");
+  const float* const* p = m.p;
+  hipStream_t s = ctx->stream;
+  char* ws = (char*)workspace;
+  float* partial = (float*)(ws + pl.partial);
+  float* rec = (float*)(ws + pl.rec);
+  float* scratch_c = (float*)(ws + pl.sums) + 2 * 704;   // 1024 floats of scratch behind the sums block
+  const int bf = (prec == DFA_PREC_BF16) ? 1 : 0;
+  DropCfg nodrop{};
+  // ---- decoder block 4
+  DFA_HIP_CHECK(ctx, launch_cae_dec4_bwd(prec, ws + pl.d[2], p[42], drecon, ws + pl.dd[2], partial, B, pl.Hd[2], pl.Wd[2], T, F, s));
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, cae_dec4_bwd_blocks(), 132, 1.0f, rec, s, nullptr));
+  DFA_HIP_CHECK(ctx, hipMemcpyAsync(grads[28], rec, 128 * 4, hipMemcpyDeviceToDevice, s));
+  DFA_HIP_CHECK(ctx, hipMemcpyAsync(grads[29], rec + 128, 4, hipMemcpyDeviceToDevice, s));
+  // ---- decoder blocks 3, 2, 1
+  for (int l = 2; l >= 0; --l) {
+    const float* const* q = p + 24 + 6 * l;
+    const int Hin = pl.Hd[l] / 2, Win = (l == 1) ? (pl.Wd[l] - 1) / 2 : pl.Wd[l] / 2;
+    const int Cin = kDCin[l], Cout = kDC[l];
+    const long P = (long)B * Hin * Win;
+    St st = stat_of(ws, pl, 4 + l, Cout);
+    float* sm = sums_of(ws, pl, 4 + l);
+    DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_DIRECT, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], nullptr, ws + pl.dd[l], partial, sm,
+                                     ws + pl.dzd[l], B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s));
+    hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[16 + 4 * l + 2], grads[16 + 4 * l + 3], Cout);
+    {  // ConvTranspose2d bias gradient = channel sums of dz over ALL output pixels (the output_padding column included)
+      int ppb;
+      const size_t npix = (size_t)B * pl.Hd[l] * pl.Wd[l];
+      const int nblk = cl_stats_blocks(npix, &ppb);
+      DFA_HIP_CHECK(ctx, launch_cl_stats(prec, ws + pl.dzd[l], partial, npix, Cout, s));
+      DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nblk, Cout * 2, 1.0f, scratch_c, s, nullptr));
+      hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, scratch_c, scratch_c + 512, grads[16 + 4 * l + 1], Cout);
+    }
+    DFA_HIP_CHECK(ctx, launch_pixel_unshuffle(prec, ws + pl.dzd[l], ws + pl.zp, B, Hin, Win, pl.Wd[l], Cout, s));
+    float* wq = (float*)(ws + pl.wq);
+    DFA_HIP_CHECK(ctx, launch_convt_w_to_q(q[0], wq, Cin, Cout, s));
+    // data gradient: dX[P x Cin] = Zp[P x 4Cout] . Wq^T
+    float* xf = (float*)(ws + pl.xf);
+    DFA_HIP_CHECK(ctx, launch_gemm_f32(bf, ws + pl.zp, 4 * Cout, 1, 0, wq, 1, 4 * Cout, xf, (int)P, Cin, 4 * Cout, 1, s));
+    void* dx = (l == 0) ? ws + pl.de[3] : ws + pl.dd[l - 1];
+    DFA_HIP_CHECK(ctx, launch_cast_from_f32(prec, xf, dx, (size_t)P * Cin, s));
+    // weight gradient: dWq[Cin x 4Cout] = X^T . Zp   (K = P, split over workgroups)
+    const void* xin = (l == 0) ? ws + pl.e[3] : ws + pl.d[l - 1];
+    DFA_HIP_CHECK(ctx, launch_gemm_f32(bf, xin, 1, Cin, bf, ws + pl.zp, 4 * Cout, 1, partial, Cin, 4 * Cout, (int)P, kGemmSplit, s));
+    float* dwq = (float*)(ws + pl.dwq);
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, kGemmSplit, Cin * 4 * Cout, 1.0f, dwq, s, nullptr));
+    DFA_HIP_CHECK(ctx, launch_convt_q_to_w(dwq, grads[16 + 4 * l], Cin, Cout, s));
+  }
+  // ---- encoder blocks 4, 3, 2
+  for (int l = 3; l >= 1; --l) {
+    St st = stat_of(ws, pl, l, kEC[l]);
+    float* sm = sums_of(ws, pl, l);
+    DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL22, ws + pl.z[l], st.mean, st.invstd, p[6 * l + 2], p[6 * l + 3], nullptr, ws + pl.de[l], partial, sm,
+                                     ws + pl.dz[l], B, pl.H[l], pl.W[l], kEC[l], nodrop, s));
+    hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], kEC[l]);
+    if (l == 3) {
+      for (int co = 0; co < 2; ++co)
+        for (int ci = 0; ci < 2; ++ci)
+          DFA_HIP_CHECK(ctx, launch_wgrad3x3_window(prec, 64, 128, 128, 256, 64 * ci, 128 * co, ws + pl.dz[3], ws + pl.e[2], partial, grads[12],
+                                                    ci == 0 ? grads[13] : nullptr, B, pl.H[3], pl.W[3], kWgradWGs, s));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, kEC[l - 1], kEC[l], ws + pl.dz[l], ws + pl.e[l - 1], partial, grads[4 * l], grads[4 * l + 1], B,
+                                         pl.H[l], pl.W[l], kWgradWGs, s));
+    }
+    ConvArgs a{};
+    a.in = ws + pl.dz[l]; a.wpack = m.tdg[l - 1].wpack; a.bias = m.tdg[l - 1].bias; a.out = ws + pl.de[l - 1];
+    a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l - 1]; a.relu = 0; a.zero_page = ctx->zero_page;
+    hipError_t e = (l == 3) ? launch_cae_dgrad4(prec, a, (float*)(ws + pl.raw), s)
+                 : (l == 2) ? launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s) : launch_train_dgrad2(prec, a, s);
+    DFA_HIP_CHECK(ctx, e);
+  }
+  // ---- encoder block 1 (z1 recomputed from x; upstream through the 2x2 average pool)
+  {
+    St st = stat_of(ws, pl, 0, 32);
+    float* sm = sums_of(ws, pl, 0);
+    const int nb1 = conv1_train_blocks(B, T, F);
+    float* scratch = partial + (size_t)nb1 * 320;
+    DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], st.mean, st.invstd, p[2], p[3],
+                                          nullptr, ws + pl.de[0], prec, partial, B, T, F, nodrop, s, 2));
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm, s, scratch));
+    hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[2], grads[3], 32);
+    DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_WGRAD, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], st.mean, st.invstd, p[2], p[3],
+                                          sm, ws + pl.de[0], prec, partial, B, T, F, nodrop, s, 2));
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, rec, s, scratch));
+    hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, rec, grads[0], grads[1]);
+  }
+  DFA_HIP_CHECK(ctx, hipGetLastError());
+  return DFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// conv3x3_inst_cae_train.hip -- conv3x3_mfma instantiations of the ConvAutoencoder training step: encoder blocks 2-4
+// forward storing the pre-BatchNorm output, and their data gradients.  Wide layers are covered by 64-input-channel
+// launches chained through fp32 partial sums (EPI_RAW / ACCIN), as in conv3x3_inst_cae.hip / conv3x3_inst_train.hip.
+#include "dfa_internal.h"
+
+namespace dfa {
+
+// forward, pre-BN output z (statistics are taken by cl_stats_kernel afterwards)
+hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  if (cin == 32) {
+    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 1>(a, s);
+    return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_PLAIN, 1>(a, s);
+  }
+  if (cin == 64) {
+    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1>(a, s);
+    return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, false, true>(a, s);
+  }
+  // cin == 128: two 64-channel halves; a.wpack holds the two images back to back
+  const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
+  ConvArgs p1 = a, p2 = a;
+  p1.in_pix_bytes = p2.in_pix_bytes = (int)(128 * es);
+  p1.in_ch_off_bytes = 0;
+  p2.in_ch_off_bytes = (int)(64 * es);
+  p1.raw_out = raw_tmp;
+  p2.acc_in = raw_tmp;
+  p2.wpack = a.wpack + (size_t)(a.COUT / 32) * 9 * nkg * 64;
+  hipError_t e;
+  if (prec == DFA_PREC_BF16) {
+    e = launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_RAW, 1>(p1, s);
+    if (e != hipSuccess) return e;
+    return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true>(p2, s);
+  }
+  e = launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_RAW, 1, false, true>(p1, s);
+  if (e != hipSuccess) return e;
+  return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true, true>(p2, s);
+}
+
+// data gradient of encoder block 4: dz4 [.,.,256] -> de3 [.,.,128]; four 64-channel launches chained through raw_tmp.
+// a.wpack: four [128/32][9][64/KG][64] images (channel windows 0-63, 64-127, 128-191, 192-255 of the 256 inputs)
+hipError_t launch_cae_dgrad4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
+  const size_t img = (size_t)(128 / 32) * 9 * nkg * 64;
+  for (int c = 0; c < 4; ++c) {
+    ConvArgs p = a;
+    p.in_pix_bytes = (int)(256 * es);
+    p.in_ch_off_bytes = (int)(64 * c * es);
+    p.wpack = a.wpack + img * c;
+    p.raw_out = raw_tmp;
+    p.acc_in = raw_tmp;
+    hipError_t e;
+    if (prec == DFA_PREC_BF16) {
+      if (c == 0) e = launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_RAW, 1>(p, s);
+      else if (c < 3) e = launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_RAW, 1, true>(p, s);
+      else e = launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true>(p, s);
+    } else {
+      if (c == 0) e = launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_RAW, 1, false, true>(p, s);
+      else if (c < 3) e = launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_RAW, 1, true, true>(p, s);
+      else e = launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true, true>(p, s);
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+}  // namespace dfa

@@ -19,6 +19,7 @@ struct ConvTArgs {
   const float* bias;   // [COUT] folded
   void* out;           // [B][2H][2W+opad_w][COUT] T
   int B, H, W, COUT, opad_w;
+  int no_relu;         // 1: store bias + sum without the ReLU (train mode: BatchNorm runs as its own pass)
 };
 
 template <typename T, int CIN, int MSUB>
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ob = obase[ms * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
-        if (ob >= 0) out[(size_t)(ob + oshift) * COUT + co] = cvt_out<T>(fmaxf(acc[i] + bv, 0.f));
+        if (ob >= 0) out[(size_t)(ob + oshift) * COUT + co] = cvt_out<T>(a.no_relu ? acc[i] + bv : fmaxf(acc[i] + bv, 0.f));
       }
     }
   }

@@ -71,6 +71,11 @@ struct CaeState {
   float *w1 = nullptr, *b1 = nullptr;
   PackedConv enc[3];   // encoder blocks 2-4
   PackedConv dec[3];   // decoder blocks 1-3 (ConvTranspose2d images)
+  // train mode (cae_train_api.hip): raw forward images, data-gradient images, raw ConvTranspose2d images
+  void* train_packed = nullptr;
+  float *tw1 = nullptr, *tb1 = nullptr;
+  PackedConv tenc[3], tdg[3], tdec[3];
+  int train_prec = -1, train_B = 0, train_T = 0;
 };
 
 }  // namespace dfa
@@ -143,7 +148,10 @@ hipError_t launch_pack_conv3x3_dgrad(const float* w, int cin, int cout, int co_o
                                      float* bias, hipStream_t s);
 hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float* g, const float* beta,
                                      const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
-                                     float* bias, hipStream_t s);
+                                     float* bias, hipStream_t s, int fold = 1);
+// gemm_f32.hip
+hipError_t launch_gemm_f32(int a_bf16, const void* A, int64_t sam, int64_t sak, int b_bf16, const void* Bm, int64_t sbk,
+                           int64_t sbn, float* C, int M, int N, int K, int ksplit, hipStream_t s);
 // conv1.hip
 hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
                         const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s,
@@ -173,7 +181,8 @@ hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias,
 hipError_t launch_cae_enc1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu,
                            const float* sigma, const float* w1, const float* b1, void* out, int prec, int B, int T, int F,
                            hipStream_t s);
-hipError_t launch_cae_opad_col(void* out, const float* bias, int prec, int rows, int Wo, int C, hipStream_t s);
+hipError_t launch_cae_opad_col(void* out, const float* bias, int prec, int rows, int Wo, int C, hipStream_t s,
+                               int no_relu = 0);
 int cae_dec4_blocks(int T, int W3);
 hipError_t launch_cae_dec4_mse(const void* d3, int prec, const float* w4, const float* b4, const void* x, int x_dtype,
                                int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon,
@@ -189,6 +198,11 @@ hipError_t launch_reduce_partials_strided(const float* partial, int nparts, int 
 hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, void* out, int B, int H, int W, int C, const DropCfg& dc,
                                     hipStream_t s);
+int cl_stats_blocks(size_t npix, int* pix_per_block);
+hipError_t launch_cl_stats(int prec, const void* z, float* partial, size_t npix, int C, hipStream_t s);
+hipError_t launch_bn_relu_pool(int prec, int pool, const void* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, void* out, int B, int H, int W, int C,
+                               hipStream_t s);
 hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
                                 const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
@@ -205,7 +219,20 @@ int conv1_train_blocks(int B, int T, int F);
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
-                              int T, int F, const DropCfg& dc, hipStream_t s);
+                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1);
+// cae_train.hip
+hipError_t launch_pixel_unshuffle(int prec, const void* dz, void* zp, int B, int H, int W, int Wo, int C, hipStream_t s);
+hipError_t launch_convt_w_to_q(const float* w, float* wq, int cin, int cout, hipStream_t s);
+hipError_t launch_convt_q_to_w(const float* dwq, float* dw, int cin, int cout, hipStream_t s);
+int cae_dec4_bwd_blocks();
+hipError_t launch_cae_dec4_bwd(int prec, const void* d3, const float* w4, const float* drecon, void* dd3, float* partial,
+                               int B, int H3, int W3, int T, int F, hipStream_t s);
+hipError_t launch_cast_from_f32(int prec, const float* src, void* dst, size_t n, hipStream_t s);
+hipError_t launch_reduce_wgrad_window(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
+                                      int ci_off, int co_off, float* dw, hipStream_t s);
+hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, int cout_total, int ci_off, int co_off,
+                                  const void* dz, const void* a, float* partial, float* dw, float* db, int B, int H,
+                                  int W, int nwg, hipStream_t s);
 hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
                            float* db, int B, int H, int W, int nwg, hipStream_t s);
 // conv3x3_inst_*.hip

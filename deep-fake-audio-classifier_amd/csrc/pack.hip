@@ -92,13 +92,13 @@ template <typename T>
 __global__ void fold_pack_convt2x2_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                           const float* __restrict__ g, const float* __restrict__ beta,
                                           const float* __restrict__ mean, const float* __restrict__ var, int cin,
-                                          int cout, uint4* __restrict__ wpack, float* __restrict__ bias) {
+                                          int cout, uint4* __restrict__ wpack, float* __restrict__ bias, int fold) {
   constexpr int KG = 32 / (int)sizeof(T);
   constexpr int EPL = KG / 2;
   const int nkg = cin / KG;
   const int total = (4 * cout / 32) * nkg * 64;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cout) bias[i] = (b[i] - mean[i]) * (g[i] / sqrtf(var[i] + kBnEps)) + beta[i];
+  if (i < cout) bias[i] = fold ? (b[i] - mean[i]) * (g[i] / sqrtf(var[i] + kBnEps)) + beta[i] : b[i];
   if (i >= total) return;
   const int lane = i & 63;
   int rest = i >> 6;
@@ -106,7 +106,7 @@ __global__ void fold_pack_convt2x2_kernel(const float* __restrict__ w, const flo
   const int slice = rest / nkg;
   const int n = slice * 32 + (lane & 31), hh = lane >> 5;
   const int q = n / cout, co = n - q * cout;
-  const float s = g[co] / sqrtf(var[co] + kBnEps);
+  const float s = fold ? g[co] / sqrtf(var[co] + kBnEps) : 1.f;
   T v[EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
@@ -118,17 +118,17 @@ __global__ void fold_pack_convt2x2_kernel(const float* __restrict__ w, const flo
 
 hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float* g, const float* beta,
                                      const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
-                                     float* bias, hipStream_t s) {
+                                     float* bias, hipStream_t s, int fold) {
   const int kg = (prec == DFA_PREC_BF16) ? 16 : 8;
   int total = (4 * cout / 32) * (cin / kg) * 64;
   if (total < cout) total = cout;
   dim3 grid((total + 255) / 256), block(256);
   if (prec == DFA_PREC_BF16)
     hipLaunchKernelGGL(fold_pack_convt2x2_kernel<bf16_t>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
-                       bias);
+                       bias, fold);
   else
     hipLaunchKernelGGL(fold_pack_convt2x2_kernel<float>, grid, block, 0, s, w, b, g, beta, mean, var, cin, cout, wpack,
-                       bias);
+                       bias, fold);
   return hipGetLastError();
 }
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ void ld8f<bf16_t>(const bf16_t* p, float* v) {
 // gradient da1 is one 16/32-byte load per thread, the dropout mask costs two Philox calls per 8 elements, and the x taps
 // are LDS broadcasts.  Every thread keeps its 8 channels' weights, BN constants and accumulators in registers and walks
 // 8 pixels of each 8 x 64 tile; sums are combined across the 64 pixel lanes at the end (shuffles, then LDS).
-template <typename TX, typename T, int MODE>
+template <typename TX, typename T, int MODE, int POOLW = 1>
 __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__ x, int64_t sb, int64_t st, int64_t sf,
                                                           const float* __restrict__ w, const float* __restrict__ bconv,
                                                           const float* __restrict__ mean,
@@ -107,13 +107,20 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
 #pragma unroll
       for (int c = 0; c < 8; ++c) g[c] = 0.f;
       const int to = t >> 1;
-      if (MODE != C1M_STATS && to < Ho) {
+      if (MODE != C1M_STATS && POOLW == 1 && to < Ho) {          // AvgPool2d((2,1)) + Dropout upstream (CNN2D)
         const size_t idx = (((size_t)b * Ho + to) * F + f) * 32 + q * 8;
         float d[8], ds[8];
         ld8f<T>(da1 + idx, d);
         drop_scale8(dc, idx, ds);
 #pragma unroll
         for (int c = 0; c < 8; ++c) g[c] = 0.5f * d[c] * ds[c];
+      }
+      if (MODE != C1M_STATS && POOLW == 2 && to < Ho && (f >> 1) < (F >> 1)) {   // AvgPool2d(2) upstream (CAE)
+        const size_t idx = (((size_t)b * Ho + to) * (F >> 1) + (f >> 1)) * 32 + q * 8;
+        float d[8];
+        ld8f<T>(da1 + idx, d);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) g[c] = 0.25f * d[c];
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -172,12 +179,18 @@ int conv1_train_blocks(int B, int T, int F) { (void)T; return B * C1T_GY * ((F +
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
-                              int T, int F, const DropCfg& dc, hipStream_t s) {
+                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw) {
   dim3 grid((F + C1T_C - 1) / C1T_C, C1T_GY, B), block(256);
   const float inv_n = (float)(1.0 / ((double)B * T * F));
 #define DFA_C1T(TXX, TT, MODE)                                                                                        \
-  hipLaunchKernelGGL((conv1_train_kernel<TXX, TT, MODE>), grid, block, 0, s, (const TXX*)x, sb, st, sf, w, bconv, mean, \
-                     invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n)
+  do {                                                                                                                 \
+    if (poolw == 2)                                                                                                    \
+      hipLaunchKernelGGL((conv1_train_kernel<TXX, TT, MODE, 2>), grid, block, 0, s, (const TXX*)x, sb, st, sf, w, bconv, \
+                         mean, invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n);                  \
+    else                                                                                                               \
+      hipLaunchKernelGGL((conv1_train_kernel<TXX, TT, MODE, 1>), grid, block, 0, s, (const TXX*)x, sb, st, sf, w, bconv, \
+                         mean, invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n);                  \
+  } while (0)
 #define DFA_C1T_MODES(TXX, TT)                                                                                        \
   do {                                                                                                                 \
     if (mode == C1M_STATS) DFA_C1T(TXX, TT, C1M_STATS);                                                                \

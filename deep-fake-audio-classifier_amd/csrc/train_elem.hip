@@ -103,6 +103,17 @@ __global__ void reduce_partials_strided_kernel(const float* __restrict__ partial
   out[j] = (float)s;
 }
 
+// weight-gradient window: out[(co_off+co)][ci_off+ci][tap] = sum_k partial[k*stride + (co*cin + ci)*9 + tap]
+__global__ void reduce_wgrad_window_kernel(const float* __restrict__ partial, int nparts, int stride, int cin, int cout,
+                                           int cin_total, int ci_off, int co_off, float* __restrict__ dw) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cout * cin * 9) return;
+  double s = 0.0;
+  for (int k = 0; k < nparts; ++k) s += (double)partial[(size_t)k * stride + j];
+  const int tap = j % 9, ci = (j / 9) % cin, co = j / (9 * cin);
+  dw[((size_t)(co_off + co) * cin_total + ci_off + ci) * 9 + tap] = (float)s;
+}
+
 // ---- forward: BN(batch stats) + ReLU + AvgPool2d((2,1)) + Dropout        z[B][H][W][C] -> a[B][H/2][W][C]
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_poolh2_drop_kernel(const T* __restrict__ z, const float* __restrict__ mean,
@@ -128,6 +139,76 @@ __global__ __launch_bounds__(256) void bn_relu_poolh2_drop_kernel(const T* __res
     const int c = cg * 8 + j;
     const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
     o[j] = 0.5f * (fmaxf(fmaf(z0[j], sc, sh), 0.f) + fmaxf(fmaf(z1[j], sc, sh), 0.f)) * ds[j];
+  }
+  st8<T>(out + pix * C + cg * 8, o);
+}
+
+// ---- per-channel sum / sum of squares of a channels-last tensor z[npix][C] -> partial[block][C][2]
+template <typename T>
+__global__ __launch_bounds__(256) void cl_stats_kernel(const T* __restrict__ z, float* __restrict__ partial, size_t npix,
+                                                       int C, int pix_per_block) {
+  extern __shared__ float red[];  // [PL][C][2]
+  const int CG = C >> 3, PL = 256 / CG;
+  const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (pl < PL)
+    for (size_t p = p0 + pl; p < p1; p += PL) {
+      float v[8];
+      ld8<T>(z + p * C + cg * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+    }
+  if (pl < PL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(pl * C + cg * 8 + j) * 2] = s1[j]; red[(pl * C + cg * 8 + j) * 2 + 1] = s2[j]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * C * 2 + e];
+    partial[(size_t)blockIdx.x * C * 2 + e] = s;
+  }
+}
+
+// ---- forward: BN(batch stats) + ReLU [+ AvgPool2d(2)]     z[B][H][W][C] -> out[B][H/P][W/P][C], P = 1 or 2
+template <typename T, int P>
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ out, int B,
+                                                           int H, int W, int C) {
+  const int Ho = H / P, Wo = W / P, CG = C >> 3;
+  const size_t total = (size_t)B * Ho * Wo * CG;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const size_t pix = i / CG;
+  const int fo = (int)(pix % Wo);
+  const size_t bt = pix / Wo;
+  const int to = (int)(bt % Ho), b = (int)(bt / Ho);
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 < P; ++c2) {
+      float v[8];
+      ld8<T>(z + ((((size_t)b * H + P * to + a) * W + P * fo + c2) * C + cg * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+        o[j] += fmaxf(fmaf(v[j], sc, sh), 0.f);
+      }
+    }
+  if (P == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
   }
   st8<T>(out + pix * C + cg * 8, o);
 }
@@ -192,7 +273,9 @@ __global__ void linear_bwd_kernel(const float* __restrict__ dlogits, const float
 //   SRC_MEANT: dy = (y > 0) * demb[b][c][f] / H                                   (block 3: mean over T then Linear)
 //   SRC_POOL : dy = (y > 0) * 0.5 * dropscale * da[b][t/2][f][c], rows t >= 2*(H/2) get 0   (blocks 1, 2)
 // reduce: S1[c] = sum dy, S2[c] = sum dy*xhat  (= dbeta, dgamma);  apply: dz = gamma*invstd*(dy - S1/N - xhat*S2/N).
-enum { SRC_MEANT = 0, SRC_POOL = 1 };
+//   SRC_DIRECT: dy = (y > 0) * da[b][t][f][c]                                   (CAE decoder: ReLU feeds the next layer)
+//   SRC_POOL22: dy = (y > 0) * 0.25 * da[b][t/2][f/2][c], rows/cols beyond 2*(H/2), 2*(W/2) get 0   (CAE encoder)
+enum { SRC_MEANT = 0, SRC_POOL = 1, SRC_DIRECT = 2, SRC_POOL22 = 3 };
 
 template <typename T, int SRC>
 __device__ __forceinline__ void upstream8(const float* demb, const T* da, const DropCfg& dc, int b, int t, int f, int cg,
@@ -202,6 +285,19 @@ __device__ __forceinline__ void upstream8(const float* demb, const T* da, const 
     ld8<float>(demb + ((size_t)b * W + f) * C + cg * 8, d);   // demb is [B][W][C] (linear_bwd_kernel with tc > 0)
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = d[j] * inv_h;
+  } else if (SRC == SRC_DIRECT) {
+    ld8<T>(da + (((size_t)b * H + t) * W + f) * C + cg * 8, g);
+  } else if (SRC == SRC_POOL22) {
+    const int Ho = H >> 1, Wo = W >> 1, to = t >> 1, fo = f >> 1;
+    if (to >= Ho || fo >= Wo) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = 0.f;
+      return;
+    }
+    float d[8];
+    ld8<T>(da + (((size_t)b * Ho + to) * Wo + fo) * C + cg * 8, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.25f * d[j];
   } else {
     const int Ho = H >> 1, to = t >> 1;
     if (to >= Ho) {
@@ -361,6 +457,14 @@ hipError_t launch_reduce_partials_strided(const float* partial, int nparts, int 
   return hipGetLastError();
 }
 
+hipError_t launch_reduce_wgrad_window(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
+                                      int ci_off, int co_off, float* dw, hipStream_t s) {
+  const int n = cout * cin * 9;
+  hipLaunchKernelGGL(reduce_wgrad_window_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, stride, cin, cout,
+                     cin_total, ci_off, co_off, dw);
+  return hipGetLastError();
+}
+
 hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, void* out, int B, int H, int W, int C, const DropCfg& dc,
                                     hipStream_t s) {
@@ -370,6 +474,38 @@ hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, 
     hipLaunchKernelGGL(bn_relu_poolh2_drop_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, (bf16_t*)out, B, H, W, C, dc);
   else
     hipLaunchKernelGGL(bn_relu_poolh2_drop_kernel<float>, grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, (float*)out, B, H, W, C, dc);
+  return hipGetLastError();
+}
+
+int cl_stats_blocks(size_t npix, int* pix_per_block) {
+  *pix_per_block = 4096;
+  return (int)((npix + 4095) / 4096);
+}
+
+hipError_t launch_cl_stats(int prec, const void* z, float* partial, size_t npix, int C, hipStream_t s) {
+  int ppb;
+  const int nblk = cl_stats_blocks(npix, &ppb);
+  const int PL = 256 / (C / 8);
+  const size_t lds = (size_t)PL * C * 2 * sizeof(float);
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL(cl_stats_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)z, partial, npix, C, ppb);
+  else
+    hipLaunchKernelGGL(cl_stats_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)z, partial, npix, C, ppb);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_pool(int prec, int pool, const void* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, void* out, int B, int H, int W, int C,
+                               hipStream_t s) {
+  const size_t total = (size_t)B * (H / pool) * (W / pool) * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (prec == DFA_PREC_BF16) {
+    if (pool == 2) hipLaunchKernelGGL((bn_relu_pool_kernel<bf16_t, 2>), grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, (bf16_t*)out, B, H, W, C);
+    else hipLaunchKernelGGL((bn_relu_pool_kernel<bf16_t, 1>), grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, (bf16_t*)out, B, H, W, C);
+  } else {
+    if (pool == 2) hipLaunchKernelGGL((bn_relu_pool_kernel<float, 2>), grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, (float*)out, B, H, W, C);
+    else hipLaunchKernelGGL((bn_relu_pool_kernel<float, 1>), grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, (float*)out, B, H, W, C);
+  }
   return hipGetLastError();
 }
 
@@ -421,9 +557,15 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
                          demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n);                                        \
   } while (0)
   if (prec == DFA_PREC_BF16) {
-    if (src == SRC_MEANT) DFA_BN_BWD(bf16_t, SRC_MEANT); else DFA_BN_BWD(bf16_t, SRC_POOL);
+    if (src == SRC_MEANT) DFA_BN_BWD(bf16_t, SRC_MEANT);
+    else if (src == SRC_POOL) DFA_BN_BWD(bf16_t, SRC_POOL);
+    else if (src == SRC_DIRECT) DFA_BN_BWD(bf16_t, SRC_DIRECT);
+    else DFA_BN_BWD(bf16_t, SRC_POOL22);
   } else {
-    if (src == SRC_MEANT) DFA_BN_BWD(float, SRC_MEANT); else DFA_BN_BWD(float, SRC_POOL);
+    if (src == SRC_MEANT) DFA_BN_BWD(float, SRC_MEANT);
+    else if (src == SRC_POOL) DFA_BN_BWD(float, SRC_POOL);
+    else if (src == SRC_DIRECT) DFA_BN_BWD(float, SRC_DIRECT);
+    else DFA_BN_BWD(float, SRC_POOL22);
   }
 #undef DFA_BN_BWD
   return hipGetLastError();

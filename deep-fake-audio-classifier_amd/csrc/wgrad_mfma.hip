@@ -34,7 +34,8 @@ constexpr int WG_SEG = 64;  // pixels (columns of one row) per work item
 //   CS == 2: wave w owns cs = w & 1 and taps [0,5) (w < 2) or [5,9) (w >= 2), all is.
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(const T* __restrict__ dz, const T* __restrict__ a,
-                                                               float* __restrict__ partial, int B, int H, int W) {
+                                                               float* __restrict__ partial, int B, int H, int W,
+                                                               int dzs_c, int as_c) {   // channels per pixel in memory
   constexpr int CS = COUT / 32, IS = CIN / 32;
   static_assert(CS == 4 || CS == 2, "COUT must be 64 or 128");
   constexpr int NTAP = (CS == 4) ? 9 : 5;       // max taps per wave
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(const T* __restri
     for (int e = tid; e < WG_SEG * (COUT / 8); e += 256) {
       const int p = e / (COUT / 8), cg = e % (COUT / 8);
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (f0 + p < W) widen8<T>(dz + ((((size_t)b * H + t) * W + f0 + p) * COUT + cg * 8), v);
+      if (f0 + p < W) widen8<T>(dz + ((((size_t)b * H + t) * W + f0 + p) * dzs_c + cg * 8), v);
       float4* d = reinterpret_cast<float4*>(dzs + p * COUT + cg * 8);
       d[0] = make_float4(v[0], v[1], v[2], v[3]);
       d[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(const T* __restri
       const int sl = (e / (CIN / 8)) % (WG_SEG + 2), row = e / ((CIN / 8) * (WG_SEG + 2));
       const int tt = t + row - 1, ff = f0 - 1 + sl;
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (tt >= 0 && tt < H && ff >= 0 && ff < W) widen8<T>(a + ((((size_t)b * H + tt) * W + ff) * CIN + cg * 8), v);
+      if (tt >= 0 && tt < H && ff >= 0 && ff < W) widen8<T>(a + ((((size_t)b * H + tt) * W + ff) * as_c + cg * 8), v);
       float4* d = reinterpret_cast<float4*>(as + (row * (WG_SEG + 2) + sl) * CIN + cg * 8);
       d[0] = make_float4(v[0], v[1], v[2], v[3]);
       d[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -135,7 +136,8 @@ constexpr int wg_stride(int c) { return (c * 2 % 128 == 64) ? c * 2 : c * 2 + 64
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ a,
-                                                               float* __restrict__ partial, int B, int H, int W) {
+                                                               float* __restrict__ partial, int B, int H, int W,
+                                                               int dzs_c, int as_c) {
   constexpr int CS = COUT / 32, IS = CIN / 32;
   static_assert(CS == 4 || CS == 2, "COUT must be 64 or 128");
   constexpr int NTAP = (CS == 4) ? 9 : 5;
@@ -175,14 +177,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(const bf16_t* __r
     for (int e = tid; e < 2 * WG_SEG * (COUT / 8); e += 256) {
       const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % WG_SEG, rr = e / ((COUT / 8) * WG_SEG);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (t0 + rr < H && f0 + p < W) v = *(const uint4*)(dz + ((((size_t)b * H + t0 + rr) * W + f0 + p) * COUT + cg * 8));
+      if (t0 + rr < H && f0 + p < W) v = *(const uint4*)(dz + ((((size_t)b * H + t0 + rr) * W + f0 + p) * dzs_c + cg * 8));
       *(uint4*)(dzs + (rr * WG_SEG + p) * DZS + cg * 16) = v;
     }
     for (int e = tid; e < 4 * AW * (CIN / 8); e += 256) {
       const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
       const int tt = t0 + row - 1, ff = f0 - 1 + sl;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (tt >= 0 && tt < H && ff >= 0 && ff < W) v = *(const uint4*)(a + ((((size_t)b * H + tt) * W + ff) * CIN + cg * 8));
+      if (tt >= 0 && tt < H && ff >= 0 && ff < W) v = *(const uint4*)(a + ((((size_t)b * H + tt) * W + ff) * as_c + cg * 8));
       *(uint4*)(as + (row * AW + sl) * AS + cg * 16) = v;
     }
     __syncthreads();
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(const bf16_t* __r
 
 template <int CIN, int COUT>
 static hipError_t launch_wgrad_bf16(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
-                                    hipStream_t s) {
+                                    hipStream_t s, int dzs_c, int as_c) {
   constexpr int LDS = 2 * WG_SEG * wg_stride(COUT) + 4 * (WG_SEG + 2) * wg_stride(CIN);
   auto kern = wgrad3x3_bf16_kernel<CIN, COUT>;
   static bool attr_set = false;
@@ -249,13 +251,13 @@ static hipError_t launch_wgrad_bf16(const void* dz, const void* a, float* partia
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LDS, s, (const bf16_t*)dz, (const bf16_t*)a, partial, B, H, W);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LDS, s, (const bf16_t*)dz, (const bf16_t*)a, partial, B, H, W, dzs_c, as_c);
   return hipGetLastError();
 }
 
 template <typename T, int CIN, int COUT>
 static hipError_t launch_wgrad_t(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
-                                 hipStream_t s) {
+                                 hipStream_t s, int dzs_c, int as_c) {
   constexpr int LDS = (WG_SEG * COUT + 3 * (WG_SEG + 2) * CIN) * 4;
   auto kern = wgrad3x3_mfma_kernel<T, CIN, COUT>;
   static bool attr_set = false;
@@ -264,29 +266,41 @@ static hipError_t launch_wgrad_t(const void* dz, const void* a, float* partial, 
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LDS, s, (const T*)dz, (const T*)a, partial, B, H, W);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LDS, s, (const T*)dz, (const T*)a, partial, B, H, W, dzs_c, as_c);
   return hipGetLastError();
 }
 
 // dW [COUT][CIN][3][3] and db [COUT] <- dz [B][H][W][COUT], a [B][H][W][CIN]; partial: nwg * (COUT*CIN*9 + COUT) floats
 hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
                            float* db, int B, int H, int W, int nwg, hipStream_t s) {
+  return launch_wgrad3x3_window(prec, cin, cout, cin, cout, 0, 0, dz, a, partial, dw, db, B, H, W, nwg, s);
+}
+
+// channel-window form: the kernel shapes are (cin, cout) in {(32,64), (64,128)}; a layer with more channels is covered by
+// several launches, each on the window [ci_off, ci_off+cin) x [co_off, co_off+cout) of tensors with cin_total / cout_total
+// channels per pixel.  dw is the FULL [cout_total][cin_total][9] gradient; db (may be null) the full [cout_total] one.
+hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, int cout_total, int ci_off, int co_off,
+                                  const void* dz, const void* a, float* partial, float* dw, float* db, int B, int H,
+                                  int W, int nwg, hipStream_t s) {
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  const void* dzw = (const char*)dz + (size_t)co_off * es;
+  const void* aw = (const char*)a + (size_t)ci_off * es;
   hipError_t e;
   if (prec == DFA_PREC_BF16) {
-    if (cin == 64 && cout == 128) e = launch_wgrad_bf16<64, 128>(dz, a, partial, B, H, W, nwg, s);
-    else if (cin == 32 && cout == 64) e = launch_wgrad_bf16<32, 64>(dz, a, partial, B, H, W, nwg, s);
+    if (cin == 64 && cout == 128) e = launch_wgrad_bf16<64, 128>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+    else if (cin == 32 && cout == 64) e = launch_wgrad_bf16<32, 64>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
     else return hipErrorInvalidValue;
   } else {
-    if (cin == 64 && cout == 128) e = launch_wgrad_t<float, 64, 128>(dz, a, partial, B, H, W, nwg, s);
-    else if (cin == 32 && cout == 64) e = launch_wgrad_t<float, 32, 64>(dz, a, partial, B, H, W, nwg, s);
+    if (cin == 64 && cout == 128) e = launch_wgrad_t<float, 64, 128>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+    else if (cin == 32 && cout == 64) e = launch_wgrad_t<float, 32, 64>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
     else return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   const int n = cout * cin * 9;
-  // the weight block and the bias block of the partial records are reduced by two strided launches
-  e = launch_reduce_partials_strided(partial, nwg, n + cout, 0, n, dw, s);
-  if (e != hipSuccess) return e;
-  return launch_reduce_partials_strided(partial, nwg, n + cout, n, cout, db, s);
+  // weight block: partial record [cout][cin][9] -> dw rows co_off.., columns ci_off.. of [cout_total][cin_total][9]
+  e = launch_reduce_wgrad_window(partial, nwg, n + cout, cin, cout, cin_total, ci_off, co_off, dw, s);
+  if (e != hipSuccess || !db) return e;
+  return launch_reduce_partials_strided(partial, nwg, n + cout, n, cout, db + co_off, s);
 }
 
 }  // namespace dfa

@@ -174,8 +174,70 @@ def cnn1d_train_forward(model, x):
     return Cnn1dTrainFunction.apply(x, model, *model.parameters())
 
 
+def _bind_cae(model, ctx):
+    ts = model._abi_tensors()
+    for t in ts:
+        if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("ConvAutoencoder parameters must be contiguous float32 tensors on the GPU")
+    sig = (ctx.index, tuple(t.data_ptr() for t in ts))
+    if getattr(model, "_bound", None) != sig:
+        arr = _lib.ptr_array([t.detach() for t in ts])
+        _lib.check(ctx.handle, ctx.lib.dfa_cae_set_params(ctx.handle, arr, len(ts), model.base_channels))
+        model._bound = sig
+    model._prepared = None
+
+
+class CaeTrainFunction(torch.autograd.Function):
+    """(reconstruction, latent) = ConvAutoencoder(x) in train mode; the gradient flows through the reconstruction
+    (src/train_cae.py:67-71 uses MSELoss(recon, x)); the latent map is returned for inspection only."""
+
+    @staticmethod
+    def forward(fctx, x, model, *params):
+        if x.device.type != "cuda":
+            raise RuntimeError("dfa_amd.ConvAutoencoder runs on the GPU only: move the input with .to('cuda')")
+        B, T, F = x.shape
+        ctx = _lib.Context.get(x.device)
+        with torch.cuda.device(ctx.index):
+            ctx.use_current_stream()
+            _bind_cae(model, ctx)
+            prec = _lib.PRECISIONS[model.precision]
+            nbytes = ctx.lib.dfa_cae_train_workspace_bytes(ctx.handle, B, T, F, prec)
+            if nbytes == 0:
+                raise ValueError(f"bad auto-encoder training shape (B={B}, T={T}, F={F}): need T >= 16 and F = 16k+4")
+            ws = _train_ws(model, ctx, nbytes)
+            recon = torch.empty((B, T, F), dtype=torch.float32, device=x.device)
+            latent = torch.empty((B, 8 * model.base_channels, T // 16, F // 16), dtype=torch.float32, device=x.device)
+            sb, st, sf = x.stride()
+            _lib.check(ctx.handle, ctx.lib.dfa_cae_forward_train(
+                ctx.handle, C.c_void_p(x.data_ptr()), _lib.x_dtype_code(x), B, T, F, sb, st, sf, prec, 0.1, 1,
+                C.c_void_p(recon.data_ptr()), C.c_void_p(latent.data_ptr()), None, C.c_void_p(ws.data_ptr()),
+                ws.numel()))
+            for _, bi in model._ENC:
+                model.encoder[bi].num_batches_tracked += 1
+            for _, bi in model._DEC:
+                if bi is not None:
+                    model.decoder[bi].num_batches_tracked += 1
+        fctx.model, fctx.x, fctx.ctx, fctx.ws = model, x, ctx, ws
+        fctx.mark_non_differentiable(latent)
+        return recon, latent
+
+    @staticmethod
+    def backward(fctx, drecon, _dlatent):
+        model, x, ctx, ws = fctx.model, fctx.x, fctx.ctx, fctx.ws
+        grads = [torch.empty_like(p) for p in model.parameters()]
+        B, T, F = x.shape
+        d = drecon.contiguous().float()
+        with torch.cuda.device(ctx.index):
+            ctx.use_current_stream()
+            sb, st, sf = x.stride()
+            _lib.check(ctx.handle, ctx.lib.dfa_cae_backward(
+                ctx.handle, C.c_void_p(x.data_ptr()), _lib.x_dtype_code(x), B, T, F, sb, st, sf,
+                C.c_void_p(d.data_ptr()), _lib.ptr_array(grads), len(grads), C.c_void_p(ws.data_ptr()), ws.numel()))
+        return (None, None, *grads)
+
+
 def cae_train_forward(model, x):
-    raise NotImplementedError("ConvAutoencoder training on the HIP path is not built yet (DESIGN.md section 6); eval only")
+    return CaeTrainFunction.apply(x, model, *model.parameters())
 
 
 class NativeTrainer:

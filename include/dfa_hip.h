@@ -163,6 +163,21 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
                     int64_t stride_t, int64_t stride_f, const float* mu, const float* sigma, float* recon,
                     float* latent, float* mse, void* workspace, size_t workspace_bytes);
 
+/* ConvAutoencoder training step (replaces, for src/train_cae.py:58-82, torch autograd over src/model_cae.py:32-125).
+ * forward_train: x is the (already z-scored) input; BatchNorm uses batch statistics and updates the running statistics
+ * in place when update_running_stats != 0; recon is required, latent / mse may be NULL.
+ * backward: drecon = d(loss)/d(reconstruction), device float[B*T*F] (e.g. 2*(recon-x)/(B*T*F) for MSELoss); gradients
+ * of the 30 parameters are written to grads[] in parameters() order: encoder.{0,1,4,5,8,9,12,13}.{weight,bias},
+ * decoder.{0,1,3,4,6,7}.{weight,bias}, decoder.9.{weight,bias}. */
+size_t dfa_cae_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F, int precision);
+int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                          int64_t stride_t, int64_t stride_f, int precision, float momentum,
+                          int update_running_stats, float* recon, float* latent, float* mse, void* workspace,
+                          size_t workspace_bytes);
+int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
+                     int64_t stride_f, const float* drecon, float* const* grads, int ngrads, void* workspace,
+                     size_t workspace_bytes);
+
 /* ---- shared ------------------------------------------------------------------------------------ */
 size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision);
 /* names of the device kernels a forward launches, for profile post-processing ("" when unknown) */

@@ -256,3 +256,57 @@ def test_cnn1d_train_step_matches_reference(golden, tag, eps):
     m.dropout = 0.3
     a, b = m(x), m(x)
     assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+def test_cae_train_step_matches_reference(golden):
+    """ConvAutoencoder training step: MSELoss(recon, x), backward, AdamW(lr 1e-3, wd 0.01) against the reference's own
+    autograd results (tests/golden/cae_train.npz, B=2, T=32)."""
+    from dfa_amd.model_cae import ConvAutoencoder
+    _, g = golden("cae_train")
+    m = ConvAutoencoder()
+    m.load_state_dict({k[len("init.sd."):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("init.sd.")})
+    m = m.to("cuda").train()
+    x = torch.from_numpy(g["ls0.x"]).to("cuda")
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    recon, latent = m(x)
+    assert recon.shape == x.shape and latent.shape == (2, 256, 2, 11)
+    loss = torch.nn.MSELoss()(recon, x)
+    opt.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["ls0.loss"], rtol=2e-5)
+    noise = {f"encoder.{i}.bias" for i in (0, 4, 8, 12)} | {f"decoder.{i}.bias" for i in (0, 3, 6)}
+    for name, p in m.named_parameters():
+        want, got = g[f"ls0.grad.{name}"], p.grad.cpu().numpy()
+        wname = name.replace("bias", "weight")
+        if name in noise:                     # bias in front of a batch-statistics BatchNorm: exactly-zero gradient
+            floor = 1e-4 * np.abs(g[f"ls0.grad.{wname}"]).max() + 1e-6
+            assert np.abs(got).max() < floor and np.abs(want).max() < floor, name
+            continue
+        scale = max(np.abs(want).max(), 1e-6)
+        np.testing.assert_allclose(got, want, atol=3e-4 * scale + 1e-7, rtol=5e-3, err_msg=name)
+    opt.step()
+    for k, v in m.state_dict().items():
+        want = g[f"ls0.after1.{k}"]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(want), k
+        elif k in noise:
+            assert np.abs(v.cpu().numpy() - g["init.sd." + k]).max() <= 1.02e-3 + 1e-6
+        elif k.endswith("running_mean"):
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=1.1e-3, rtol=2e-4, err_msg=k)
+        else:
+            # Adam divides by sqrt(v): an element whose gradient sits at the fp32 rounding-noise floor moves by up to
+            # +-lr whatever its sign -- allow a vanishing fraction of such elements, each bounded by lr
+            got = v.cpu().numpy()
+            close = np.isclose(got, want, atol=3e-5, rtol=3e-4)
+            assert close.mean() > 0.9999, (k, 1.0 - close.mean())
+            assert np.abs(got - want).max() <= 1.05e-3, k
+    # bf16 storage mode runs and stays close
+    m16 = ConvAutoencoder(precision="bf16")
+    m16.load_state_dict({k[len("init.sd."):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("init.sd.")})
+    m16 = m16.to("cuda").train()
+    r16, _ = m16(x)
+    l16 = torch.nn.MSELoss()(r16, x)
+    l16.backward()
+    assert abs(l16.item() - float(g["ls0.loss"])) < 0.02 * float(g["ls0.loss"])
+    gw = m16.decoder[9].weight.grad.cpu().numpy()
+    assert np.abs(gw - g["ls0.grad.decoder.9.weight"]).max() < 0.1 * np.abs(g["ls0.grad.decoder.9.weight"]).max()
