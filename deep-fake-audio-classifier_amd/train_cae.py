@@ -1,0 +1,121 @@
+"""Auto-encoder trainer -- counterpart of src/train_cae.py (same CLI flags and artefacts: cae_best.pt / cae_last.pt in
+the reference checkpoint format plus normalizer.pt), with the model step on the MI355X HIP path.
+
+Bonafide (label == 1) utterances only; inputs are z-scored per feature dim with statistics fitted on the bonafide
+training set; loss = MSELoss(reconstruction, input); AdamW(lr 1e-4, wd 1e-4); ReduceLROnPlateau on the validation MSE;
+best checkpoint = lowest validation MSE; early stopping on patience."""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+from torch import nn
+from torch.utils.data import DataLoader
+
+from .dataset_cae import BonafideDataset, FeatureNormalizer, build_normalizer
+from .model_cae import ConvAutoencoder
+from .training import save_checkpoint
+
+
+def train_one_epoch(model, dataloader, criterion, optimizer, device="cuda"):
+    """Mean reconstruction loss over the epoch (src/train_cae.py:58-82); the loss stays on the device until the end."""
+    model.train()
+    total, count = None, 0
+    for x in dataloader:
+        x = x.to(device, non_blocking=True)
+        recon, _ = model(x)
+        loss = criterion(recon, x)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        term = loss.detach().double() * x.size(0)
+        total = term if total is None else total + term
+        count += x.size(0)
+    return (float(total.item()) / count) if count else None
+
+
+@torch.no_grad()
+def validate_reconstruction(model, dataloader, device="cuda"):
+    """Mean per-sample MSE on a (bonafide) validation loader (src/train_cae.py:85-105), via the fused score kernel."""
+    model.eval()
+    total, count = None, 0
+    for x in dataloader:
+        mse = model.score(x.to(device, non_blocking=True)).double().sum()
+        total = mse if total is None else total + mse
+        count += x.size(0)
+    return (float(total.item()) / count) if count else None
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Train the convolutional auto-encoder for anomaly detection (MI355X).")
+    p.add_argument("--train-features", default="data/train/features.pkl")
+    p.add_argument("--train-labels", default="data/train/labels.pkl")
+    p.add_argument("--dev-features", default="data/dev/features.pkl")
+    p.add_argument("--dev-labels", default="data/dev/labels.pkl")
+    p.add_argument("--batch-size", type=int, default=32)
+    p.add_argument("--num-workers", type=int, default=2)
+    p.add_argument("--epochs", type=int, default=80)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--weight-decay", type=float, default=1e-4)
+    p.add_argument("--early-stop", type=int, default=10)
+    p.add_argument("--lr-scheduler-patience", type=int, default=7)
+    p.add_argument("--lr-scheduler-factor", type=float, default=0.5)
+    p.add_argument("--lr-scheduler-min-lr", type=float, default=1e-6)
+    p.add_argument("--base-channels", type=int, default=32)
+    p.add_argument("--checkpoint-dir", default="checkpoints")
+    p.add_argument("--run-name", default="cae_anomaly")
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--normalizer-path", default=None)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    device = args.device
+    ckpt_dir = os.path.join(args.checkpoint_dir, args.run_name)
+    os.makedirs(ckpt_dir, exist_ok=True)
+    best_path, last_path = os.path.join(ckpt_dir, "cae_best.pt"), os.path.join(ckpt_dir, "cae_last.pt")
+    if args.normalizer_path and os.path.exists(args.normalizer_path):
+        normalizer = FeatureNormalizer.load(args.normalizer_path)
+    else:
+        normalizer = build_normalizer(args.train_features, args.train_labels)
+        normalizer.save(os.path.join(ckpt_dir, "normalizer.pt"))
+    train_ds = BonafideDataset(args.train_features, args.train_labels, normalizer=normalizer, swap_tf=True)
+    val_ds = BonafideDataset(args.dev_features, args.dev_labels, normalizer=normalizer, swap_tf=True)
+    train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
+    val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+
+    model = ConvAutoencoder(base_channels=args.base_channels, precision=args.precision).to(device)
+    criterion = nn.MSELoss()
+    optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
+        optimizer, mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience, threshold=1e-4,
+        min_lr=args.lr_scheduler_min_lr)
+    best, no_improve, last_epoch = None, 0, 0
+    for epoch in range(1, args.epochs + 1):
+        train_loss = train_one_epoch(model, train_loader, criterion, optimizer, device)
+        val_mse = validate_reconstruction(model, val_loader, device)
+        scheduler.step(val_mse)
+        is_best = best is None or val_mse < best
+        print(f"epoch {epoch}: train_mse={train_loss:.6f} val_mse={val_mse:.6f}" + ("  *best*" if is_best else ""))
+        if is_best:
+            best, no_improve = val_mse, 0
+            save_checkpoint(model, optimizer, epoch, args, best_path, scheduler=scheduler)
+        else:
+            no_improve += 1
+        last_epoch = epoch
+        if args.early_stop and no_improve >= args.early_stop:
+            break
+    save_checkpoint(model, optimizer, last_epoch, args, last_path, scheduler=scheduler)
+
+
+if __name__ == "__main__":
+    main()

@@ -310,3 +310,35 @@ def test_cae_train_step_matches_reference(golden):
     assert abs(l16.item() - float(g["ls0.loss"])) < 0.02 * float(g["ls0.loss"])
     gw = m16.decoder[9].weight.grad.cpu().numpy()
     assert np.abs(gw - g["ls0.grad.decoder.9.weight"]).max() < 0.1 * np.abs(g["ls0.grad.decoder.9.weight"]).max()
+
+
+def test_train_cae_cli_end_to_end(tmp_path):
+    """python -m dfa_amd.train_cae on synthetic pickles: the validation MSE falls and reference-format artefacts are
+    written (cae_best.pt, cae_last.pt, normalizer.pt)."""
+    import pandas as pd
+    from dfa_amd import train_cae as TC
+    from dfa_amd.training import load_checkpoint
+    g = torch.Generator().manual_seed(3)
+    base = torch.outer(torch.sin(torch.arange(180) / 11.0), torch.cos(torch.arange(321) / 29.0)) * 4.0
+
+    def make(n, tag):
+        feats = [base + 0.3 * torch.randn(180, 321, generator=g) for _ in range(n)]
+        ids = [f"{tag}{i:03d}" for i in range(n)]
+        fp, lp = str(tmp_path / f"{tag}_f.pkl"), str(tmp_path / f"{tag}_l.pkl")
+        pd.DataFrame({"uttid": ids, "features": feats}).to_pickle(fp)
+        pd.DataFrame({"uttid": ids, "label": [1] * (n - 2) + [0, 0]}).to_pickle(lp)
+        return fp, lp
+    trf, trl = make(34, "tr")
+    dvf, dvl = make(18, "dv")
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        TC.main(["--train-features", trf, "--train-labels", trl, "--dev-features", dvf, "--dev-labels", dvl, "--epochs", "4",
+                 "--batch-size", "16", "--num-workers", "0", "--lr", "1e-3", "--checkpoint-dir", str(tmp_path),
+                 "--run-name", "cae"])
+    vals = [float(l.split("val_mse=")[1].split()[0]) for l in buf.getvalue().splitlines() if "val_mse=" in l]
+    assert len(vals) == 4 and vals[-1] < vals[0]
+    for f in ("cae_best.pt", "cae_last.pt", "normalizer.pt"):
+        assert (tmp_path / "cae" / f).exists()
+    blob = load_checkpoint(str(tmp_path / "cae" / "cae_best.pt"))
+    assert "encoder.12.weight" in blob["model_state"] and "decoder.9.bias" in blob["model_state"]

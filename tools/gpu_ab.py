@@ -1,6 +1,6 @@
 """A/B the conv staging variants in one process (interleaved rounds)."""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 from dfa_amd import _lib
 dev = torch.device("cuda", 0)

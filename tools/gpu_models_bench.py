@@ -1,6 +1,6 @@
 """Throughput of the secondary paths (CNN1D, CAE score / full forward) at B=256."""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dfa_amd.model_cnn1d import CNN1D
 from dfa_amd.model_cae import ConvAutoencoder
 dev = torch.device("cuda", 0)

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dfa_amd.model import CNN2D
 from dfa_amd.training.train_step import NativeTrainer
 dev = torch.device("cuda", 0)
