@@ -149,7 +149,8 @@ const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null c
 
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return DFA_E_NULL_PTR;
-  if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value < 0 ? -1 : (value ? 1 : 0); return DFA_OK; }
+  if (strcmp(name, "lds_pipe") == 0) { ctx->lds_pipe = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value < 0 ? -1 : value; return DFA_OK; }
   return fail(ctx, DFA_E_UNSUPPORTED, "unknown option '%s'", name);
 }
 
@@ -270,14 +271,14 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ConvArgs a{};
     a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;
     a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma));
+    DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
   }
   {
     ScopedSlot ts(ctx, 2);
     ConvArgs a{};
     a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma));
+    DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
   }
   {
     ScopedSlot ts(ctx, 3);
@@ -437,7 +438,7 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
     ConvArgs a{};
     a.in = e[l]; a.wpack = m.enc[l].wpack; a.bias = m.enc[l].bias; a.out = e[l + 1];
     a.B = B; a.H = pl.H[l + 1]; a.W = pl.W[l + 1]; a.COUT = ecout[l]; a.relu = 1;
-    hipError_t err = (l == 0) ? launch_cae_enc2(prec, a, s) : (l == 1) ? launch_cae_enc3(prec, a, s)
+    hipError_t err = (l == 0) ? launch_cae_enc2(prec, a, s, ctx->lds_pipe) : (l == 1) ? launch_cae_enc3(prec, a, s, ctx->lds_pipe)
                                                                         : launch_cae_enc4(prec, a, (float*)(ws + pl.raw_off), s);
     DFA_HIP_CHECK(ctx, err);
   }

@@ -8,13 +8,17 @@
 
 namespace dfa {
 
-hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s) {
-  if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_2X2, 2>(a, s);
+hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe) {
+  if (prec == DFA_PREC_BF16)
+    return pipe ? launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_2X2, 2>(a, s)
+                : launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_2X2, 2, false, false, false, 0>(a, s);
   return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_POOL_2X2, 1>(a, s);
 }
 
-hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s) {
-  if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_POOL_2X2, 2>(a, s);
+hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe) {
+  if (prec == DFA_PREC_BF16)
+    return pipe ? launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_POOL_2X2, 2>(a, s)
+                : launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_POOL_2X2, 2, false, false, false, 0>(a, s);
   return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_POOL_2X2, 1>(a, s);
 }
 

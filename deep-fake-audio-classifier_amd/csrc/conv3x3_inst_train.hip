@@ -32,7 +32,7 @@ hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipS
     p2.in_ch_off_bytes = 64 * 2;
     p2.acc_in = raw_tmp;
     p2.wpack = a.wpack + (size_t)(64 / 32) * 9 * 4 * 64;
-    return launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_PLAIN, 2, true, false>(p2, s);
+    return launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_PLAIN, 1, true, true>(p2, s);
   }
   ConvArgs p1 = a;
   p1.in_pix_bytes = 128 * 4;

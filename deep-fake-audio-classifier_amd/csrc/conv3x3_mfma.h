@@ -44,8 +44,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace dfa {
 
@@ -128,6 +130,35 @@ struct Mma<float> {
   }
 };
 
+// ---- explicit LDS fragment pipeline.  hipcc schedules "ds_read_b128 -> s_waitcnt lgkmcnt(0) -> MFMA" with ONE fragment
+// buffer (every MFMA pair eats the full LDS latency), so the fragment reads are issued through inline asm PFD reads
+// ahead of their use and retired with counted waits.  LDS operations complete in order, so "lgkmcnt(N)" guarantees
+// everything older than the N youngest reads has landed; reads the compiler adds on its own only make a wait stricter.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int OFF, bool PIPE>
+__device__ __forceinline__ u32x4_t lds_frag(unsigned addr) {
+  u32x4_t v;
+  if constexpr (PIPE) {
+    constexpr int LO = OFF & 0xFFFF, HI = OFF - LO;   // the DS offset field is 16 bits
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + HI), "n"(LO));
+  } else {   // compiler-scheduled read (it places its own s_waitcnt)
+    v = *(const u32x4_t*)((const __attribute__((address_space(3))) char*)(size_t)(addr + OFF));
+  }
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4_t& v) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(u32x4_t& a, u32x4_t& b, u32x4_t& c, u32x4_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
 template <typename T, int CIN, int NSL, int MG, int RP, int EPI>
 struct ConvCfg {
   static constexpr int ES = sizeof(T);
@@ -154,8 +185,11 @@ struct ConvCfg {
   static_assert(CIN % KG == 0, "CIN must be a multiple of the k-group");
 };
 
+#ifdef DFA_STAMPS
+__device__ long long g_diag[2048 * 4 * 8];
+#endif
 template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false,
-          bool STATS = false>
+          bool STATS = false, int PFD = -1>
 __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvArgs a) {
   static_assert(MT == 1, "strips are 32 columns wide");
   using C = ConvCfg<T, CIN, NSL, MG, RP, EPI>;
@@ -194,6 +228,13 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
 #pragma unroll
       for (int kg = 0; kg < NKG; ++kg) w[tap][kg] = wp[(tap * NKG + kg) * 64];
   }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
+  // PFD > 0: asm-pipelined fragment reads, PFD reads in flight; 0: compiler-scheduled reads; -1: pipelined (depth 4) for
+  // the two-waves-per-SIMD bf16 kernels.  The one-wave-per-SIMD kernels keep weights in AGPRs and spill; there the
+  // compiler-scheduled form is used (an fp32 ACCIN kernel produced wrong sums with pipelined reads under that register
+  // pressure) -- every pipelined instantiation is checked bit-for-bit against its PFD = 0 twin on the GPU.
+  constexpr bool PIPE = PFD > 0 || (PFD < 0 && MINW >= 2 && sizeof(T) == 2);
+  constexpr int PF = PIPE ? (PFD > 0 ? PFD : 4) : 1;
   float* bias_lds = (float*)(smem + C::RING_BYTES);
   if (tid < NSL * 32) bias_lds[tid] = a.bias[cout_base + tid];
 
@@ -268,6 +309,14 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
   const bool col_ok = col < W;
 
   const int niter = (H + BR - 1) / BR;
+#ifdef DFA_STAMPS
+  long long seg[6] = {0, 0, 0, 0, 0, 0};
+  long long t_prev = __builtin_amdgcn_s_memtime();
+  const long long t_begin = t_prev;
+  auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg[k] += t - t_prev; t_prev = t; };
+#else
+  auto stamp = [&](int) {};
+#endif
   if (DMA) {
     stage_dma(0, 0);
     stage_dma(1, 1);
@@ -277,6 +326,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
     stage_load(1);
     stage_store(1);
   }
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // one unit: output rows t0 = BR*it + 2*RPI, t0+1; PH = it % 3 (ring phase), both compile-time
@@ -295,29 +345,44 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         acc0[4 * g] = v0.x; acc0[4 * g + 1] = v0.y; acc0[4 * g + 2] = v0.z; acc0[4 * g + 3] = v0.w;
         acc1[4 * g] = v1.x; acc1[4 * g + 1] = v1.y; acc1[4 * g + 2] = v1.z; acc1[4 * g + 3] = v1.w;
       }
-    } else {  // bias is the accumulator's initial value (EPI_RAW partial sums carry it into the ACCIN launch)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *(const float4*)(bias_lds + nsl * 32 + 8 * g + 4 * h);
-        acc0[4 * g] = bv.x; acc0[4 * g + 1] = bv.y; acc0[4 * g + 2] = bv.z; acc0[4 * g + 3] = bv.w;
-        acc1[4 * g] = bv.x; acc1[4 * g + 1] = bv.y; acc1[4 * g + 2] = bv.z; acc1[4 * g + 3] = bv.w;
-      }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // input row key q = BR*it + 2*RPI + i  (input row t = q - 1)
-      const int ringrow = (BR * PH + 2 * RPI + i) % (3 * BR);   // compile-time after unrolling
-      const char* rowp = smem + ringrow * ROWB;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-        for (int kg = 0; kg < NKG; ++kg) {
-          const uint4 xv = *(const uint4*)(rowp + (xa[dx] ^ (kg << 5)));
-          if (i <= 2) acc0 = Mma<T>::run(w[i * 3 + dx][kg], xv, acc0);
-          if (i >= 1) acc1 = Mma<T>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
-        }
+    constexpr int NR = 12 * NKG;   // fragment reads of a unit, in (row i, dx, kg) order
+    u32x4_t xb[PF];
+    auto step = [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      if constexpr (s < NR) {
+        constexpr int i = s / (3 * NKG), dx = (s / NKG) % 3, kg = s % NKG;   // input row key q = BR*it + 2*RPI + i
+        constexpr int ringrow = (BR * PH + 2 * RPI + i) % (3 * BR);
+        xb[s % PF] = lds_frag<ringrow * ROWB, PIPE>(lds0 + (xa[dx] ^ (kg << 5)));
       }
+      if constexpr (s >= PF - 1) {
+        constexpr int c = s - (PF - 1);
+        constexpr int i = c / (3 * NKG), dx = (c / NKG) % 3, kg = c % NKG;
+        constexpr int young = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
+        if constexpr (PIPE) lds_wait<young>(xb[c % PF]);
+        const uint4 xv = __builtin_bit_cast(uint4, xb[c % PF]);
+        if constexpr (i <= 2) acc0 = Mma<T>::run(w[i * 3 + dx][kg], xv, acc0);
+        if constexpr (i >= 1) acc1 = Mma<T>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
+      }
+    };
+    if (!ACCIN) {  // bias is the accumulator's initial value (EPI_RAW partial sums carry it into the ACCIN launch)
+      const unsigned ba = lds0 + C::RING_BYTES + (nsl * 32 + 4 * h) * 4;
+      u32x4_t b0 = lds_frag<0, PIPE>(ba), b1 = lds_frag<32, PIPE>(ba), b2 = lds_frag<64, PIPE>(ba), b3 = lds_frag<96, PIPE>(ba);
+      static_for(std::make_integer_sequence<int, PF - 1>{}, step);   // first fragment reads go out behind the bias reads
+      if constexpr (PIPE) lds_wait4<PF - 1>(b0, b1, b2, b3);
+      const u32x4_t bq[4] = {b0, b1, b2, b3};
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc0[4 * g + e] = acc1[4 * g + e] = __uint_as_float(bq[g][e]);
+    } else {
+      static_for(std::make_integer_sequence<int, PF - 1>{}, step);
     }
+    static_for(std::make_integer_sequence<int, NR>{}, [&](auto s_c) {
+      step(std::integral_constant<int, decltype(s_c)::value + PF - 1>{});
+    });
 
+    stamp(1);
     // ---- fused epilogue.  Register i <-> channel nb + (i&3) + 8*(i>>2) + 4*h of pixel (row, col).
     if (EPI == EPI_POOL_H2) {
       const int Ho = H >> 1, to = t0 >> 1;
@@ -426,6 +491,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
     if (pf) {
       if (DMA) stage_dma(it + 2, (PH + 2) % 3); else stage_load(it + 2);
     }
+    stamp(0);
 #pragma unroll
     for (int uu = 0; uu < C::UPW; ++uu) {
       if (MG == 1) {
@@ -441,17 +507,30 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         }
       }
     }
+    stamp(2);
     if (pf && !DMA) stage_store((PH + 2) % 3);
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA pieces of block it+2 have landed
+    stamp(3);
     __syncthreads();
+    stamp(4);
   };
   static_assert(C::UPW <= 2 && MG <= 2, "unit dispatch above covers UPW <= 2, MG <= 2");
 
+  stamp(5);   // prologue
   for (int it = 0; it < niter; it += 3) {
     iteration(std::integral_constant<int, 0>{}, it);
     if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
     if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
   }
 
+#ifdef DFA_STAMPS
+  if (lane == 0 && blockIdx.x < 2048 && EPI == EPI_MEAN_T) {
+    long long* d = g_diag + ((size_t)blockIdx.x * 4 + (wave & 3)) * 8;
+    for (int k = 0; k < 6; ++k) d[k] = seg[k];
+    d[6] = t_begin;
+    d[7] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   if (STATS && a.stats_partial) {
     // per-channel sums: reduce over the 32 pixel lanes of each half-wave, then over the M groups through LDS
 #pragma unroll
@@ -495,12 +574,12 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
 
 // host-side launcher
 template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false,
-          bool STATS = false>
+          bool STATS = false, int PFD = -1>
 hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<T, CIN, NSL, MG, RP, EPI>;
   ConvArgs a = a0;
   a.nstrips = (a.W + 31) / 32;
-  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN, DMA, STATS>;
+  auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN, DMA, STATS, PFD>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -509,6 +588,22 @@ hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
   }
   dim3 grid(a.B * a.nstrips, a.COUT / (NSL * 32), 1), block(C::NT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, C::LDS_BYTES, stream, a);
+#ifdef DFA_STAMPS
+  if (EPI == EPI_MEAN_T && sizeof(T) == 2) {
+    static int calls = 0;
+    if (++calls == 40) {
+      static long long hbuf[2048 * 4 * 8];
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag), sizeof(hbuf));
+      const int nw = (grid.x < 2048 ? grid.x : 2048) * 4;
+      double m[8] = {0}; long long tmin = hbuf[6], tmax = hbuf[7];
+      for (int i = 0; i < nw; ++i) { for (int k = 0; k < 6; ++k) m[k] += hbuf[i * 8 + k]; m[6] += hbuf[i * 8 + 7] - hbuf[i * 8 + 6];
+        if (hbuf[i * 8 + 6] < tmin) tmin = hbuf[i * 8 + 6]; if (hbuf[i * 8 + 7] > tmax) tmax = hbuf[i * 8 + 7]; }
+      fprintf(stderr, "[stamps] waves %d  mean cycles/wave: stage_issue %.0f  mfma_loop %.0f  epilogue %.0f  vmcnt_wait %.0f  barrier %.0f  prologue %.0f  lifetime %.0f  kernel span %lld\n",
+              nw, m[0] / nw, m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw, m[6] / nw, tmax - tmin);
+    }
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -85,6 +85,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
+  int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
@@ -236,11 +237,11 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
 hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
                            float* db, int B, int H, int W, int nwg, hipStream_t s);
 // conv3x3_inst_*.hip
-hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = 0);
-hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = 0);
+hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
+hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 struct ConvTArgs;
-hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s);
-hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1);
+hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
 hipError_t launch_cae_dec(int prec, int cin, const ConvTArgs& a, hipStream_t s);
 

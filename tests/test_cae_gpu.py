@@ -52,6 +52,25 @@ def test_cae_bf16_mode_close(golden):
     np.testing.assert_allclose(model.score(x).cpu().numpy(), g["t321.mse"], rtol=2e-2)
 
 
+def test_cae_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
+    """bf16 encoder blocks 2/3 use asm-pipelined LDS reads: bit-identical to the compiler-scheduled twins."""
+    from dfa_amd import _lib
+    sd, g = golden("cae_eval")
+    model = _model(sd, "bf16")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.from_numpy(g["t321.x"]).to("cuda"), torch.randn(64, 321, 180, generator=gen).to("cuda")]
+    try:
+        for x in xs:
+            ctx.set_option("lds_pipe", 0)
+            ref_r, ref_l = model(x)
+            ctx.set_option("lds_pipe", 1)
+            got_r, got_l = model(x)
+            assert torch.equal(ref_l, got_l) and torch.equal(ref_r, got_r), tuple(x.shape)
+    finally:
+        ctx.set_option("lds_pipe", 1)
+
+
 def test_cae_full_batch_independence_and_oracle(golden):
     sd, _ = golden("cae_eval")
     model = _model(sd)

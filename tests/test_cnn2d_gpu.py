@@ -179,4 +179,29 @@ def test_cnn2d_lds_dma_staging_matches_register_staging(golden):
                 dma_l, dma_e = model(x, return_embedding=True)
                 assert torch.equal(ref_e, dma_e) and torch.equal(ref_l, dma_l), (prec, tag)
     finally:
-        ctx.set_option("conv_dma", 0)
+        ctx.set_option("conv_dma", -1)
+
+
+def test_cnn2d_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
+    """The asm-pipelined fragment reads (conv3x3_mfma.h, PFD > 0) change the instruction schedule only: every pipelined
+    bf16 kernel must be bit-identical to its compiler-scheduled twin (lds_pipe = 0), for both staging paths, at small
+    sizes and at the headline batch."""
+    from dfa_amd import _lib
+    sd, g = golden("cnn2d_eval")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    model = _model_from_sd(sd, precision="bf16")
+    gen = torch.Generator().manual_seed(7)
+    big = (torch.randn(256, 180, 321, generator=gen) * 3.0).to(device="cuda", dtype=torch.bfloat16).transpose(1, 2)
+    xs = [torch.from_numpy(g[f"{t}.x_stored"]).to("cuda").transpose(1, 2) for t in ("t321", "t7")] + [big]
+    try:
+        for dma in (0, 1):
+            ctx.set_option("conv_dma", dma)
+            for x in xs:
+                ctx.set_option("lds_pipe", 0)
+                ref_l, ref_e = model(x, return_embedding=True)
+                ctx.set_option("lds_pipe", 1)
+                got_l, got_e = model(x, return_embedding=True)
+                assert torch.equal(ref_e, got_e) and torch.equal(ref_l, got_l), (dma, tuple(x.shape))
+    finally:
+        ctx.set_option("conv_dma", -1)
+        ctx.set_option("lds_pipe", 1)

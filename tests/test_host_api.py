@@ -193,3 +193,22 @@ def test_flat_ingest_roundtrip(tmp_path):
     assert torch.equal(f16.tensor(), torch.stack(list(feats["features"])).to(torch.bfloat16))
     parts = list(FlatBatcher(ff.tensor(), ff.labels, 4, device="cpu"))
     assert [b[0].shape[0] for b in parts] == [4, 2]
+
+
+def test_pipelined_lds_reads_are_never_touched_in_flight():
+    """Static check of the compiled gfx950 assembly (tools/check_lds_pipeline.py): between an asm-issued ds_read_b128
+    and the counted s_waitcnt that retires it, no instruction may read or write the destination registers."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_lds_pipeline", os.path.join(root, "tools", "check_lds_pipeline.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not os.path.exists(chk.HIPCC):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(root, "deep-fake-audio-classifier_amd", "csrc")
+    total = 0
+    for name in ("conv3x3_inst_cnn2d.hip", "conv3x3_inst_cae.hip"):
+        kernels, nreads, violations = chk.check_asm(chk.compile_to_asm(os.path.join(csrc, name)))
+        assert not violations, violations[:5]
+        total += nreads
+    assert total > 0          # the pipelined instantiations exist
