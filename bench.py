@@ -215,7 +215,7 @@ def main():
                          "traffic": pmc_traffic(prec) if B == B_PER_GPU else None,
                          "kernel_ms": round(k_ms, 4), "launches_timed": n3},
             "kernel_ms": {name: round(ms / max(n, 1), 4) for name, (ms, n) in
-                          zip(("conv1", "block2_mfma", "block3_mfma", "linear"), slots)},
+                          zip(("conv1", "block2_mfma_or_fused_blocks12", "block3_mfma", "linear"), slots)},
             "logits_sample": [round(float(v), 4) for v in out[:3, 0].float().cpu()],
         }
         sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}

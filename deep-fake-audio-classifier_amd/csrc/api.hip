@@ -149,6 +149,7 @@ const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null c
 
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return DFA_E_NULL_PTR;
+  if (strcmp(name, "fuse_conv1") == 0) { ctx->fuse_conv1 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "lds_pipe") == 0) { ctx->lds_pipe = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value < 0 ? -1 : value; return DFA_OK; }
   return fail(ctx, DFA_E_UNSUPPORTED, "unknown option '%s'", name);
@@ -211,7 +212,8 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // one allocation: w1[288] b1[32] | bias2[64] bias3[128] | wpack2 | wpack3   (sized for fp32, the larger mode)
   const size_t w2_bytes = (size_t)64 * 32 * 9 * 4, w3_bytes = (size_t)128 * 64 * 9 * 4;
-  const size_t need = align_up((288 + 32 + 64 + 128) * sizeof(float), 256) + w2_bytes + w3_bytes;
+  const size_t c1_bytes = 4 * 64 * 16 + 256;   // block-1 MFMA operands + bias of the fused kernel
+  const size_t need = align_up((288 + 32 + 64 + 128) * sizeof(float), 256) + w2_bytes + w3_bytes + c1_bytes;
   if (!m.packed) {
     DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, need));
     m.packed_bytes = need;
@@ -224,8 +226,11 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   char* wp = base + align_up((288 + 32 + 64 + 128) * sizeof(float), 256);
   m.c2.wpack = (uint4*)wp;
   m.c3.wpack = (uint4*)(wp + w2_bytes);
+  m.c1pack = (uint4*)(wp + w2_bytes + w3_bytes);
+  m.c1bias = (float*)(wp + w2_bytes + w3_bytes + 4 * 64 * 16);
   const float* const* p = m.p;
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, ctx->stream));
+  DFA_HIP_CHECK(ctx, launch_pack_conv1_mfma(m.w1, m.b1, m.c1pack, m.c1bias, ctx->stream));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 0, 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream, 1, 0.5f));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 0, 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
   m.prepared_prec = precision;
@@ -262,11 +267,17 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   void* a2 = ws + pl.a2_off;
   float* emb = embedding ? embedding : (float*)(ws + pl.emb_off);
   hipStream_t s = ctx->stream;
-  {
+  // bf16 mode on bf16 features: blocks 1 and 2 run as one kernel and a1 stays on chip (timing slot 1)
+  const bool fused12 = prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && ctx->fuse_conv1;
+  if (fused12) {
+    ScopedSlot ts(ctx, 1);
+    DFA_HIP_CHECK(ctx, launch_conv12_fused(x, stride_b, stride_t, stride_f, m.c1pack, m.c1bias, m.c2.wpack, m.c2.bias, a2,
+                                           B, T, F, s));
+  } else {
     ScopedSlot ts(ctx, 0);
     DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.w1, m.b1, a1, prec, B, T, F, s));
   }
-  {
+  if (!fused12) {
     ScopedSlot ts(ctx, 1);
     ConvArgs a{};
     a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;

@@ -77,6 +77,10 @@ __device__ __forceinline__ float cvt_out<float>(float f) { return f; }
 template <>
 __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float f) { return float_to_bf16(f); }
 
+// ReLU as ONE instruction (v_med3_f32 x, 0, +inf).  fmaxf() costs two: the compiler canonicalises the operand first.
+// Not inline asm: the compiler's MFMA -> VALU hazard nops do not cover asm statements.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+
 enum { EPI_POOL_H2 = 0, EPI_POOL_2X2 = 1, EPI_MEAN_T = 2, EPI_PLAIN = 3, EPI_RAW = 4 };
 
 struct ConvArgs {
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
   // pressure) -- every pipelined instantiation is checked bit-for-bit against its PFD = 0 twin on the GPU.
   constexpr bool PIPE = PFD > 0 || (PFD < 0 && MINW >= 2 && sizeof(T) == 2);
   constexpr int PF = PIPE ? (PFD > 0 ? PFD : 4) : 1;
+  constexpr bool EARLY_RELU = PIPE && (EPI == EPI_POOL_H2 || EPI == EPI_POOL_2X2 || EPI == EPI_MEAN_T);
   float* bias_lds = (float*)(smem + C::RING_BYTES);
   if (tid < NSL * 32) bias_lds[tid] = a.bias[cout_base + tid];
 
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       }
     }
     constexpr int NR = 12 * NKG;   // fragment reads of a unit, in (row i, dx, kg) order
+    constexpr int S_RELU0 = 9 * NKG + (NKG >= 2 ? 2 : 1);         // acc0's last MFMA is consume step 9*NKG - 1
     u32x4_t xb[PF];
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
@@ -363,6 +369,10 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         const uint4 xv = __builtin_bit_cast(uint4, xb[c % PF]);
         if constexpr (i <= 2) acc0 = Mma<T>::run(w[i * 3 + dx][kg], xv, acc0);
         if constexpr (i >= 1) acc1 = Mma<T>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
+        if constexpr (EARLY_RELU && c == S_RELU0) {   // rows 0..2 of acc0 are complete: its ReLU hides under acc1's last MFMAs
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc0[e] = relu1(acc0[e]);
+        }
       }
     };
     if (!ACCIN) {  // bias is the accumulator's initial value (EPI_RAW partial sums carry it into the ACCIN launch)
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       const int Ho = H >> 1, to = t0 >> 1;
       float v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc0[i], 0.f) + fmaxf(acc1[i], 0.f);   // 1/2 is in the weights
+      for (int i = 0; i < 16; ++i) v[i] = (EARLY_RELU ? acc0[i] : relu1(acc0[i])) + relu1(acc1[i]);   // 1/2 is in the weights
       T* o = (T*)a.out + (((size_t)b * Ho + to) * W + col) * COUT + nb;
       const bool ok = (to < Ho) && col_ok;
       if (sizeof(T) == 4) {
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       float v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float s = fmaxf(acc0[i], 0.f) + fmaxf(acc1[i], 0.f);      // 1/4 is in the weights
+        const float s = (EARLY_RELU ? acc0[i] : relu1(acc0[i])) + relu1(acc1[i]);      // 1/4 is in the weights
         v[i] = s + __shfl_xor(s, 1, 64);                                  // + the neighbouring column (lane r ^ 1)
       }
       const int fo = col >> 1;
@@ -429,9 +439,13 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         }
       }
     } else if (EPI == EPI_MEAN_T) {
-      const float k0 = (t0 < H) ? 1.f : 0.f, k1 = (t0 + 1 < H) ? 1.f : 0.f;
+      if (t0 + 1 < H) {          // wave-uniform: only the last row pair of an odd H takes the other branch
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cs[i] += k0 * fmaxf(acc0[i], 0.f) + k1 * fmaxf(acc1[i], 0.f);
+        for (int i = 0; i < 16; ++i) cs[i] += (EARLY_RELU ? acc0[i] : relu1(acc0[i])) + relu1(acc1[i]);
+      } else if (t0 < H) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cs[i] += (EARLY_RELU ? acc0[i] : relu1(acc0[i]));
+      }
     } else if (EPI == EPI_RAW) {
       float* o0 = a.raw_out + (((size_t)b * H + t0) * W + col) * COUT + nb + 4 * h;
       float* o1 = o0 + (size_t)W * COUT;
@@ -447,8 +461,8 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       float v0[16], v1[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        v0[i] = a.relu ? fmaxf(acc0[i], 0.f) : acc0[i];
-        v1[i] = a.relu ? fmaxf(acc1[i], 0.f) : acc1[i];
+        v0[i] = a.relu ? relu1(acc0[i]) : acc0[i];
+        v1[i] = a.relu ? relu1(acc1[i]) : acc1[i];
       }
       if (STATS) {
         const float m0 = r0ok ? 1.f : 0.f, m1 = r1ok ? 1.f : 0.f;

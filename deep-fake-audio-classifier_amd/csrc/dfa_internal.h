@@ -40,6 +40,8 @@ struct Cnn2dState {
   size_t packed_bytes = 0;
   float* w1 = nullptr;     // [32][9] folded
   float* b1 = nullptr;     // [32]
+  uint4* c1pack = nullptr; // [4][64] bf16 hi/lo A operands of the fused block 1+2 kernel (conv12_fused.hip)
+  float* c1bias = nullptr; // [32]
   PackedConv c2, c3;
   // train mode (train_api.hip)
   void* train_packed = nullptr;
@@ -85,6 +87,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
+  int fuse_conv1 = 1;          // bf16 mode + bf16 input: blocks 1 and 2 in one kernel (conv12_fused.hip); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
@@ -237,6 +240,9 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
 hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
                            float* db, int B, int H, int W, int nwg, hipStream_t s);
 // conv3x3_inst_*.hip
+hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pack, float* c1bias, hipStream_t s);
+hipError_t launch_conv12_fused(const void* x, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack, const float* c1bias,
+                               const uint4* wpack2, const float* bias2, void* a2, int B, int T, int F, hipStream_t s);
 hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 struct ConvTArgs;

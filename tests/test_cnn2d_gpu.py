@@ -98,6 +98,46 @@ def test_cnn2d_bf16_mode_close_and_rank_preserving(golden):
     np.testing.assert_allclose(got_bf16in, want, atol=0.10, rtol=0)
 
 
+def test_cnn2d_fused_blocks_1_2_match_two_kernel_path_and_oracle(golden):
+    """bf16 mode on bf16 features runs blocks 1+2 as one kernel (conv12_fused.hip: block 1 on the matrix cores from
+    hi/lo-split weights, a1 kept in LDS).  It must agree with the two-kernel path to well inside the bf16-mode error
+    (the only difference is the summation order inside block 1, which flips a few bf16 roundings of a1), for both
+    feature layouts, ragged widths (F = 65, 40: last strip 5 / 10 columns), short T, and batch-independently."""
+    from dfa_amd import _lib
+    from dfa_amd.model import CNN2D
+    sd, g = golden("cnn2d_eval")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(5)
+    sdn = {k: np.asarray(v) for k, v in sd.items()}
+    cases = [("t321", torch.from_numpy(g["t321.x_stored"]), True), ("t7", torch.from_numpy(g["t7.x_stored"]), True),
+             ("btf", torch.randn(3, 50, 180, generator=gen), False), ("F65", torch.randn(2, 65, 33, generator=gen), True),
+             ("F40", torch.randn(2, 40, 18, generator=gen), True), ("T4", torch.randn(2, 180, 4, generator=gen), True),
+             ("b64", torch.randn(64, 180, 321, generator=gen) * 3, True)]
+    try:
+        for name, stored, is_bft in cases:
+            xb = stored.to("cuda").to(torch.bfloat16)
+            xb = xb.transpose(1, 2) if is_bft else xb        # [B,T,F] view of [B,F,T] storage, or contiguous [B,T,F]
+            F = xb.shape[2]
+            model = _model_from_sd(sd, precision="bf16") if F == 180 else CNN2D(in_features=F, precision="bf16").to("cuda").eval()
+            ctx.set_option("fuse_conv1", 0)
+            l0, e0 = model(xb, return_embedding=True)
+            ctx.set_option("fuse_conv1", 1)
+            l1, e1 = model(xb, return_embedding=True)
+            scale = max(1.0, float(l0.abs().max()))
+            assert float((l0 - l1).abs().max()) <= 2e-3 * scale, name
+            assert float((e0 - e1).abs().max()) <= 4e-3 * max(1.0, float(e0.abs().max())), name
+            if F == 180 and xb.shape[0] <= 8:           # both paths sit at the same distance from the fp32 oracle
+                ref = O.cnn2d_forward(sdn, xb.float().cpu().numpy()).reshape(-1)
+                d0 = np.abs(l0.cpu().numpy().reshape(-1) - ref).max()
+                d1 = np.abs(l1.cpu().numpy().reshape(-1) - ref).max()
+                assert d1 <= 0.06 and d1 <= 1.5 * d0 + 1e-3, (name, d0, d1)
+            if name == "b64":                           # batch independence of the fused path
+                one, _ = model(xb[17:18], return_embedding=True)
+                assert torch.equal(one, l1[17:18])
+    finally:
+        ctx.set_option("fuse_conv1", 1)
+
+
 def test_cnn2d_batch_independence_full_size(golden):
     """BASELINE configs[1] shape [256,321,180]: every utterance's logit must equal the logit it gets in a batch of
     its own (eval mode has no cross-sample op) -- a size-independent property checked at the full benchmark size."""
@@ -194,6 +234,7 @@ def test_cnn2d_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
     big = (torch.randn(256, 180, 321, generator=gen) * 3.0).to(device="cuda", dtype=torch.bfloat16).transpose(1, 2)
     xs = [torch.from_numpy(g[f"{t}.x_stored"]).to("cuda").transpose(1, 2) for t in ("t321", "t7")] + [big]
     try:
+        ctx.set_option("fuse_conv1", 0)          # the stand-alone block-2 kernel has the twins (bf16 inputs would fuse it away)
         for dma in (0, 1):
             ctx.set_option("conv_dma", dma)
             for x in xs:
@@ -205,3 +246,4 @@ def test_cnn2d_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
     finally:
         ctx.set_option("conv_dma", -1)
         ctx.set_option("lds_pipe", 1)
+        ctx.set_option("fuse_conv1", 1)

@@ -5,7 +5,7 @@ them with counted `s_waitcnt lgkmcnt(N)`.  Between the read and the wait the com
 already hold the data; if register pressure makes it copy or spill such a register (v_accvgpr_write, scratch_store,
 v_mov ...) before the wait, it moves stale data.  This script compiles a .hip file to gfx950 assembly and verifies, per
 kernel, that no instruction touches the destination of an in-flight asm read before a wait has retired it, and that
-no asm read is in flight across a branch or label.
+no asm read is in flight across a loop back-edge (forward skips are covered by the linear scan).
 
 usage: check_lds_pipeline.py file.hip [more.hip ...]      (exit code 1 on a violation)
 """
@@ -45,11 +45,11 @@ def compile_to_asm(path):
 def check_asm(text):
     """returns (kernels checked, asm reads seen, list of violations)"""
     violations, kernels, nreads = [], 0, 0
-    kernel, queue, in_asm = None, [], False   # queue: issue-ordered LDS ops, entries = (is_asm_read, dest regs, line no)
+    kernel, queue, in_asm, labels = None, [], False, set()   # queue: issue-ordered LDS ops, entries = (is_asm_read, dest regs, line no)
     for ln, raw in enumerate(text.split("\n"), 1):
         line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
         if raw.startswith("_Z") and raw.rstrip().split(";")[0].rstrip().endswith(":"):
-            kernel, queue = raw.split(":")[0], []
+            kernel, queue, labels = raw.split(":")[0], [], set()
             kernels += 1
             continue
         if kernel is None or not line:
@@ -64,9 +64,12 @@ def check_asm(text):
             kernel = None
             continue
         inflight = set().union(*[q[1] for q in queue if q[0]]) if queue else set()
-        if line.endswith(":") or line.startswith("s_cbranch") or line.startswith("s_branch"):
-            if inflight:
-                violations.append((kernel, ln, "asm LDS read in flight across control flow: " + line))
+        if line.endswith(":"):                      # label: a forward skip lands here, the linear scan covers both paths
+            labels.add(line[:-1])
+            continue
+        if line.startswith("s_cbranch") or line.startswith("s_branch"):
+            if inflight and line.split()[-1] in labels:   # backward branch (loop): nothing may be in flight
+                violations.append((kernel, ln, "asm LDS read in flight across a loop back-edge: " + line))
             continue
         m = LGKM.search(line)
         if line.startswith("s_waitcnt"):
