@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 METRIC = "utterances/sec fwd (2D-CNN, [B,T=321,F=180]) at 1/2/4/8 GPU; dev EER parity"
 B_PER_GPU, T, F = 256, 321, 180
 FLOPS_PER_UTT = 3_218_376_960          # 2 x MAC, conv + linear
+BLOCK3_KERNEL = {"bf16": "conv3_m16_meant_kernel", "fp32": "conv3x3_mfma_kernel<float,64,...>"}
 BLOCK3_FLOPS_PER_UTT = 2 * 1_061_683_200  # Conv2d 64->128 on (80,180): the dominant kernel (66 % of the FLOPs)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
 
@@ -39,9 +40,9 @@ def pmc_traffic(prec):
         blob = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
     except (OSError, ValueError):
         return None
-    tag = "dfa::bf16_t, 64, 4" if prec == "bf16" else "float, 64, 4"
+    tag = "conv3_m16_meant_kernel" if prec == "bf16" else "conv3x3_mfma_kernel<float, 64, 4"
     for name, rec in blob.get("kernels", {}).items():
-        if "conv3x3_mfma_kernel<" + tag in name:
+        if tag in name and "[" not in name:
             return rec.get("hbm_bytes_per_launch")
     return None
 
@@ -209,7 +210,7 @@ def main():
         results[prec] = {
             "value": world * B * args.steps / dt,
             "ms_per_step": dt / args.steps * 1e3,
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (CNN2D block 3, 64->128, +BN+ReLU+mean_T)",
+            "roofline": {"bound": "mfma", "kernel": BLOCK3_KERNEL[prec] + " (CNN2D block 3, 64->128, +BN+ReLU+mean_T)",
                          "achieved": round(ach, 2), "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_TFLOPS[prec], 4),
                          "traffic": pmc_traffic(prec) if B == B_PER_GPU else None,

@@ -149,6 +149,7 @@ const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null c
 
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return DFA_E_NULL_PTR;
+  if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "fuse_conv1") == 0) { ctx->fuse_conv1 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "lds_pipe") == 0) { ctx->lds_pipe = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv_dma") == 0) { ctx->conv_dma = value < 0 ? -1 : value; return DFA_OK; }
@@ -184,8 +185,7 @@ int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count) {
 }
 
 const char* dfa_dominant_kernel(int model, int precision) {
-  (void)precision;
-  if (model == DFA_MODEL_CNN2D) return "conv3x3_mfma_kernel";
+  if (model == DFA_MODEL_CNN2D) return precision == DFA_PREC_BF16 ? "conv3_m16_meant_kernel" : "conv3x3_mfma_kernel";
   return "";
 }
 
@@ -212,7 +212,8 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // one allocation: w1[288] b1[32] | bias2[64] bias3[128] | wpack2 | wpack3   (sized for fp32, the larger mode)
   const size_t w2_bytes = (size_t)64 * 32 * 9 * 4, w3_bytes = (size_t)128 * 64 * 9 * 4;
-  const size_t c1_bytes = 4 * 64 * 16 + 256;   // block-1 MFMA operands + bias of the fused kernel
+  const size_t m16_bytes = (size_t)128 * 64 * 9 * 2;   // block-3 image for the 16x16x32 kernel (bf16)
+  const size_t c1_bytes = 4 * 64 * 16 + 256 + m16_bytes;   // block-1 MFMA operands + bias of the fused kernel
   const size_t need = align_up((288 + 32 + 64 + 128) * sizeof(float), 256) + w2_bytes + w3_bytes + c1_bytes;
   if (!m.packed) {
     DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, need));
@@ -228,11 +229,14 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   m.c3.wpack = (uint4*)(wp + w2_bytes);
   m.c1pack = (uint4*)(wp + w2_bytes + w3_bytes);
   m.c1bias = (float*)(wp + w2_bytes + w3_bytes + 4 * 64 * 16);
+  m.c3_m16 = (uint4*)(wp + w2_bytes + w3_bytes + 4 * 64 * 16 + 256);
   const float* const* p = m.p;
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, ctx->stream));
   DFA_HIP_CHECK(ctx, launch_pack_conv1_mfma(m.w1, m.b1, m.c1pack, m.c1bias, ctx->stream));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 0, 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream, 1, 0.5f));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 0, 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
+  if (precision == DFA_PREC_BF16)
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3_m16(p[12], p[13], p[14], p[15], p[16], p[17], 64, 128, m.c3_m16, ctx->stream));
   m.prepared_prec = precision;
   return DFA_OK;
 }
@@ -289,7 +293,12 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ConvArgs a{};
     a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
+    if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
+      a.wpack = m.c3_m16;
+      DFA_HIP_CHECK(ctx, launch_cnn2d_block3_m16(a, s));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
+    }
   }
   {
     ScopedSlot ts(ctx, 3);

@@ -42,6 +42,7 @@ struct Cnn2dState {
   float* b1 = nullptr;     // [32]
   uint4* c1pack = nullptr; // [4][64] bf16 hi/lo A operands of the fused block 1+2 kernel (conv12_fused.hip)
   float* c1bias = nullptr; // [32]
+  uint4* c3_m16 = nullptr; // block 3 weights in the 16x16x32 operand order (conv3_m16.hip), bf16 mode only
   PackedConv c2, c3;
   // train mode (train_api.hip)
   void* train_packed = nullptr;
@@ -87,6 +88,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
+  int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
   int fuse_conv1 = 1;          // bf16 mode + bf16 input: blocks 1 and 2 in one kernel (conv12_fused.hip); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
@@ -240,6 +242,9 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
 hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
                            float* db, int B, int H, int W, int nwg, hipStream_t s);
 // conv3x3_inst_*.hip
+hipError_t launch_fold_pack_conv3x3_m16(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                                        const float* var, int cin, int cout, uint4* wpack, hipStream_t s);
+hipError_t launch_cnn2d_block3_m16(const ConvArgs& a, hipStream_t s);
 hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pack, float* c1bias, hipStream_t s);
 hipError_t launch_conv12_fused(const void* x, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack, const float* c1bias,
                                const uint4* wpack2, const float* bias2, void* a2, int B, int T, int F, hipStream_t s);

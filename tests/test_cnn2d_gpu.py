@@ -138,6 +138,28 @@ def test_cnn2d_fused_blocks_1_2_match_two_kernel_path_and_oracle(golden):
         ctx.set_option("fuse_conv1", 1)
 
 
+def test_cnn2d_block3_16x16x32_kernel_matches_32x32x16_kernel(golden):
+    """bf16 block 3 runs on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); the 32x32x16 kernel computes the same fp32
+    sums in a different K order, so embeddings agree to fp32 rounding of the accumulation, not to bf16 noise."""
+    from dfa_amd import _lib
+    sd, g = golden("cnn2d_eval")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    model = _model_from_sd(sd, precision="bf16")
+    gen = torch.Generator().manual_seed(11)
+    xs = [torch.from_numpy(g[f"{t}.x_stored"]).to("cuda").transpose(1, 2) for t in ("t321", "t7")]
+    xs.append((torch.randn(32, 180, 321, generator=gen) * 3.0).to(device="cuda", dtype=torch.bfloat16).transpose(1, 2))
+    try:
+        for x in xs:
+            ctx.set_option("block3_m16", 0)
+            l0, e0 = model(x, return_embedding=True)
+            ctx.set_option("block3_m16", 1)
+            l1, e1 = model(x, return_embedding=True)
+            assert float((e0 - e1).abs().max()) <= 1e-5 * max(1.0, float(e0.abs().max())), tuple(x.shape)
+            assert float((l0 - l1).abs().max()) <= 2e-5 * max(1.0, float(l0.abs().max())), tuple(x.shape)
+    finally:
+        ctx.set_option("block3_m16", 1)
+
+
 def test_cnn2d_batch_independence_full_size(golden):
     """BASELINE configs[1] shape [256,321,180]: every utterance's logit must equal the logit it gets in a batch of
     its own (eval mode has no cross-sample op) -- a size-independent property checked at the full benchmark size."""
@@ -235,6 +257,7 @@ def test_cnn2d_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
     xs = [torch.from_numpy(g[f"{t}.x_stored"]).to("cuda").transpose(1, 2) for t in ("t321", "t7")] + [big]
     try:
         ctx.set_option("fuse_conv1", 0)          # the stand-alone block-2 kernel has the twins (bf16 inputs would fuse it away)
+        ctx.set_option("block3_m16", 0)          # ... and so does the 32x32x16 block-3 kernel
         for dma in (0, 1):
             ctx.set_option("conv_dma", dma)
             for x in xs:
@@ -247,3 +270,4 @@ def test_cnn2d_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
         ctx.set_option("conv_dma", -1)
         ctx.set_option("lds_pipe", 1)
         ctx.set_option("fuse_conv1", 1)
+        ctx.set_option("block3_m16", 1)
