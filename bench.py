@@ -42,7 +42,7 @@ def pmc_traffic(prec):
         return None
     tag = "conv3_m16_meant_kernel" if prec == "bf16" else "conv3x3_mfma_kernel<float, 64, 4"
     for name, rec in blob.get("kernels", {}).items():
-        if tag in name and "[" not in name:
+        if tag in name:
             return rec.get("hbm_bytes_per_launch")
     return None
 
