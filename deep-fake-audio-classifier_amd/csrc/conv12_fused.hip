@@ -48,6 +48,10 @@ constexpr int NX = XROWS * XCOLS;
 constexpr int NXLD = (NX + 255) / 256;
 }  // namespace c12
 
+#ifdef DFA_STAMPS
+static __device__ long long g_diag12[2048 * 4 * 8];
+#endif
+
 __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   using namespace c12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,25 +109,26 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     xcol[k] = t_fast ? e / XROWS : e % XCOLS;
   }
   const bf16_t* xb = a.x + (long long)b * a.sxb;
-  unsigned short xreg[NXLD];
+  unsigned short xreg[NXLD];   // raw loaded bits; out-of-image elements are zeroed when they are stored, not here: a
+  bool xok[NXLD];              // select on the loaded value would make the wave wait out the load latency at issue time
   auto x_load = [&](int j) {
 #pragma unroll
     for (int k = 0; k < NXLD; ++k) {
       const int t = 8 * j - 3 + xrow[k], f = f0 - 2 + xcol[k];
-      const bool ok = (k * 256 + tid < NX) && t >= 0 && t < T && f >= 0 && f < W;
-      const unsigned short v = xb[ok ? (long long)t * a.sxt + (long long)f * a.sxf : 0].v;   // clamped, branch-free
-      xreg[k] = ok ? v : (unsigned short)0;
+      xok[k] = (k * 256 + tid < NX) && t >= 0 && t < T && f >= 0 && f < W;
+      xreg[k] = xb[xok[k] ? (long long)t * a.sxt + (long long)f * a.sxf : 0].v;   // clamped address, branch-free
     }
   };
   auto x_store = [&](int buf) {   // element (row, c) is tap e of the windows of slots c - e, e = 0..2
 #pragma unroll
     for (int k = 0; k < NXLD; ++k) {
       const int base = XW_OFF + buf * XW_BYTES + xrow[k] * XW_ROWB;
+      const unsigned short v = xok[k] ? xreg[k] : (unsigned short)0;
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int s = xcol[k] - e;
         const bool ok = (k * 256 + tid < NX) && s >= 0 && s < 32;
-        *(unsigned short*)(smem + (ok ? base + s * 8 + e * 2 : DUMMY_OFF)) = xreg[k];
+        *(unsigned short*)(smem + (ok ? base + s * 8 + e * 2 : DUMMY_OFF)) = v;
       }
     }
   };
@@ -182,6 +187,14 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   const bool col_ok = (r < SW) && col < W;
   const int niter = (H + BR - 1) / BR;
 
+#ifdef DFA_STAMPS   // diagnostic build (make stamps): per-wave cycle split, printed by the launcher
+  long long seg[6] = {0, 0, 0, 0, 0, 0};
+  long long t_prev = __builtin_amdgcn_s_memtime();
+  const long long t_begin = t_prev;
+  auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg[k] += t - t_prev; t_prev = t; };
+#else
+  auto stamp = [&](int) {};
+#endif
   // ---- prologue: windows of blocks 0, 1 -> ring blocks 0, 1; windows of block 2
   __syncthreads();                 // window pads / bias written
   x_load(0); x_store(0);
@@ -246,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     static_for(std::make_integer_sequence<int, NR>{}, [&](auto s_c) {
       step(std::integral_constant<int, decltype(s_c)::value + PF - 1>{});
     });
+    stamp(1);
     // AvgPool2d((2,1)) over the row pair (the 1/2 is in the weights), 16-byte packed stores
     const int Ho = H >> 1, to = t0 >> 1;
     float v[16];
@@ -267,15 +281,27 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   // checks turn those into zeros that nobody reads): no wave-divergent or data-dependent branch in the loop.
   auto iteration = [&](auto ph_c, int it) {
     x_load(it + 3);
+    stamp(0);
     if (mg == 0) unit(ph_c, std::integral_constant<int, 0>{}, it);
     else unit(ph_c, std::integral_constant<int, 1>{}, it);
+    stamp(2);
     __syncthreads();
+    stamp(3);
   };
+  stamp(5);
   for (int it = 0; it < niter; it += 3) {
     iteration(std::integral_constant<int, 0>{}, it);
     if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
     if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
   }
+#ifdef DFA_STAMPS
+  if (lane == 0 && blockIdx.x < 2048) {
+    long long* dd = g_diag12 + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int k = 0; k < 6; ++k) dd[k] = seg[k];
+    dd[6] = t_begin;
+    dd[7] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 // A operands of the block-1 MFMAs.  Lane (ch = lane&31, hh = lane>>5), element j: k = 8*hh + j, feature row dyy = k/4,
@@ -319,6 +345,21 @@ hipError_t launch_conv12_fused(const void* x, int64_t sb, int64_t st, int64_t sf
     attr_set = true;
   }
   hipLaunchKernelGGL(conv12_fused_kernel, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
+#ifdef DFA_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 40) {
+      static long long hbuf[2048 * 4 * 8];
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag12), sizeof(hbuf));
+      const int nw = (B * a.nstrips < 2048 ? B * a.nstrips : 2048) * 4;
+      double m[8] = {0};
+      for (int i = 0; i < nw; ++i) { for (int k = 0; k < 6; ++k) m[k] += hbuf[i * 8 + k]; m[6] += hbuf[i * 8 + 7] - hbuf[i * 8 + 6]; }
+      fprintf(stderr, "[stamps conv12] waves %d  mean cycles/wave: x_load %.0f  mfma_stream %.0f  epilogue %.0f  barrier %.0f  prologue %.0f  lifetime %.0f\n",
+              nw, m[0] / nw, m[1] / nw, m[2] / nw, m[3] / nw, m[5] / nw, m[6] / nw);
+    }
+  }
+#endif
   return hipGetLastError();
 }
 

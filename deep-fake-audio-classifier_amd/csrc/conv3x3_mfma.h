@@ -190,7 +190,7 @@ struct ConvCfg {
 };
 
 #ifdef DFA_STAMPS
-__device__ long long g_diag[2048 * 4 * 8];
+static __device__ long long g_diag[2048 * 4 * 8];
 #endif
 template <typename T, int CIN, int NSL, int MG, int RP, int MT, int EPI, int MINW, bool ACCIN = false, bool DMA = false,
           bool STATS = false, int PFD = -1>
