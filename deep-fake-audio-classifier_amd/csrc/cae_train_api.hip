@@ -69,7 +69,7 @@ CaeTrainPlan plan_cae_train(int B, int T, int F, int prec) {
   p.wq = take((size_t)256 * 512 * 4);
   p.dwq = take((size_t)256 * 512 * 4);
   p.rec = take(1024 * 4);
-  size_t pb = (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 128) * 4;
+  size_t pb = (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 256) * 4;
   pb = std::max(pb, (size_t)kGemmSplit * 256 * 512 * 4);
   pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 320 * 4);
   int ppb;

@@ -66,7 +66,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 320 * 4);   // conv1 passes + 2nd-level scratch
   int ppb;
   pb = std::max(pb, (size_t)bn_bwd_blocks(B, p.H1, F, &ppb) * 128 * 2 * 4);  // BN backward partials
-  pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 128) * 4);   // weight-gradient partials
+  pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 256) * 4);   // weight-gradient partials
   p.partial_bytes = pb;
   p.partial = take(pb);
   p.total = off;

@@ -240,6 +240,355 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(const bf16_t* __r
   if (h == 0 && tap0 == 0) out[(size_t)COUT * CIN * 9 + cs * 32 + r] = dbsum;
 }
 
+// ---- bf16 kernel, second version.  The first one gave every wave ONE 32-channel dz slice: each transposed activation
+// fragment (2 x ds_read_b64_tr_b16) fed a single MFMA, LDS reads were waited for one by one at one wave per SIMD, and the
+// tiles were staged synchronously: 0.29 PFLOP/s.  Here a wave owns 18 accumulator tiles = 9 taps x 2 dz slices (288
+// AGPRs at one wave per SIMD): a k-step of 16 pixels reads 2 dz + 9 activation fragments for 18 MFMAs (0.6 fragment
+// reads per MFMA, all issued before the first MFMA needs them), and the next work item's tiles are fetched into
+// registers while the current one is computed (double-buffered LDS, one barrier per item).
+//   KSPLIT = false (64 -> 128): the four waves are (ci slice, dz-slice pair) on the same pixels.
+//   KSPLIT = true  (32 -> 64):  18 tiles are the whole gradient: the four waves take different k-steps (pixels) of the
+//                               item and each writes its own partial record.
+template <int CIN, int COUT, int SEG, bool KSPLIT>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_v2_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ a,
+                                                                  float* __restrict__ partial, int B, int H, int W,
+                                                                  int dzs_c, int as_c) {
+  constexpr int CS = COUT / 32, IS = CIN / 32;
+  static_assert(KSPLIT ? (IS == 1 && CS == 2) : (IS * CS == 8 && IS == 2), "tile split covers (32,64) and (64,128)");
+  constexpr int DZS = wg_stride(COUT), AS = wg_stride(CIN);   // bytes per pixel row in LDS
+  constexpr int AW = SEG + 2;
+  constexpr int DZ_BYTES = 2 * SEG * DZS, A_BYTES = 4 * AW * AS, BUF_BYTES = DZ_BYTES + A_BYTES;
+  constexpr int NDZ = (2 * SEG * (COUT / 8) + 255) / 256, NA = (4 * AW * (CIN / 8) + 255) / 256;
+  constexpr int NKS = 2 * (SEG / 16);                        // k-steps of an item
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int is = KSPLIT ? 0 : (wave & 1);
+  const int cs0 = KSPLIT ? 0 : 2 * (wave >> 1);
+  const int i16 = lane & 15, qrow = i16 >> 2, pq = i16 & 3, chalf = (lane >> 4) & 1;
+  const int dz_lane = (8 * h + qrow) * DZS + (cs0 * 32 + 16 * chalf + 4 * pq) * 2;
+  const int a_lane = (8 * h + qrow) * AS + (is * 32 + 16 * chalf + 4 * pq) * 2;
+
+  f32x16_t acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+  float dbsum[2] = {0.f, 0.f};
+
+  const int nseg = (W + SEG - 1) / SEG, nrp = (H + 1) / 2;
+  const long nitems = (long)B * nrp * nseg;
+  uint4 sdz[NDZ], sa[NA];
+  auto load_item = [&](long item) {       // global -> registers (zeros outside the image)
+    const int seg = (int)(item % nseg);
+    const long bt = item / nseg;
+    const int t0 = 2 * (int)(bt % nrp), b = (int)(bt / nrp);
+    const int f0 = seg * SEG;
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int e = k * 256 + tid;
+      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
+      const bool ok = e < 2 * SEG * (COUT / 8) && t0 + rr < H && f0 + p < W;
+      const uint4 v = *(const uint4*)(dz + (ok ? (((size_t)b * H + t0 + rr) * W + f0 + p) * dzs_c + cg * 8 : 0));
+      sdz[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int e = k * 256 + tid;
+      const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
+      const int tt = t0 + row - 1, ff = f0 - 1 + sl;
+      const bool ok = e < 4 * AW * (CIN / 8) && tt >= 0 && tt < H && ff >= 0 && ff < W;
+      const uint4 v = *(const uint4*)(a + (ok ? (((size_t)b * H + tt) * W + ff) * as_c + cg * 8 : 0));
+      sa[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_item = [&](int buf) {        // registers -> LDS tiles of buffer `buf`
+    char* dzb = smem + buf * BUF_BYTES;
+    char* ab = dzb + DZ_BYTES;
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int e = k * 256 + tid;
+      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
+      if (e < 2 * SEG * (COUT / 8)) *(uint4*)(dzb + (rr * SEG + p) * DZS + cg * 16) = sdz[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int e = k * 256 + tid;
+      const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
+      if (e < 4 * AW * (CIN / 8)) *(uint4*)(ab + (row * AW + sl) * AS + cg * 16) = sa[k];
+    }
+  };
+  auto tr8 = [&](const char* p0, int stride4) {   // 8 consecutive pixels of the lane's channel: two transposed reads
+    const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+    const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + stride4));
+    const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
+    return make_uint4(u0.x, u0.y, u1.x, u1.y);
+  };
+  auto kstep = [&](const char* dzb, const char* ab, int rr, int ks) {
+    uint4 av[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      av[c] = tr8(dzb + (rr * SEG + ks * 16) * DZS + dz_lane + c * 64, 4 * DZS);
+      if (KSPLIT || is == 0) {
+        const unsigned u[4] = {av[c].x, av[c].y, av[c].z, av[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dbsum[c] += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const uint4 bv = tr8(ab + ((rr + dy) * AW + ks * 16 + dx) * AS + a_lane, 4 * AS);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[tap][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av[c]),
+                                                              __builtin_bit_cast(bf16x8_t, bv), acc[tap][c], 0, 0, 0);
+    }
+  };
+
+  long item = blockIdx.x;
+  if (item < nitems) { load_item(item); store_item(0); }
+  __syncthreads();
+  for (int n = 0; item < nitems; item += gridDim.x, ++n) {
+    const long next = item + gridDim.x;
+    if (next < nitems) load_item(next);
+    const char* dzb = smem + (n & 1) * BUF_BYTES;
+    const char* ab = dzb + DZ_BYTES;
+    if (KSPLIT) {
+#pragma unroll
+      for (int j = 0; j < NKS / 4; ++j) {
+        const int kidx = wave + 4 * j;
+        kstep(dzb, ab, kidx / (SEG / 16), kidx % (SEG / 16));
+      }
+    } else {
+#pragma unroll
+      for (int kidx = 0; kidx < NKS; ++kidx) kstep(dzb, ab, kidx / (SEG / 16), kidx % (SEG / 16));
+    }
+    if (next < nitems) store_item((n + 1) & 1);
+    __syncthreads();
+  }
+
+  constexpr size_t REC = (size_t)COUT * CIN * 9 + COUT;
+  float* out = partial + (KSPLIT ? (size_t)blockIdx.x * 4 + wave : (size_t)blockIdx.x) * REC;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (cs0 + c) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, ci = is * 32 + r;
+        out[((size_t)co * CIN + ci) * 9 + tap] = acc[tap][c][i];
+      }
+  if (KSPLIT || is == 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float v = dbsum[c] + __shfl_xor(dbsum[c], 32, 64);
+      if (h == 0) out[(size_t)COUT * CIN * 9 + (cs0 + c) * 32 + r] = v;
+    }
+  }
+}
+
+// ---- bf16 kernel, third version: two waves per SIMD and asm-pipelined transposed reads.  v2 at one wave per SIMD left
+// the compiler's "two reads -> s_waitcnt lgkmcnt(0) -> two MFMAs" schedule fully exposed (and it shuttled accumulators
+// between AGPRs and VGPRs): 0.56 PFLOP/s.  Here the workgroup has 8 waves, each owning 9 accumulator tiles (the nine taps
+// of one (ci slice, dz slice) pair, 144 VGPRs, no AGPRs), so a k-step is 1 dz + 9 activation fragments for 9 MFMAs; the
+// fragment reads (2 x ds_read_b64_tr_b16 each) run PF fragments ahead through inline asm with counted lgkmcnt waits,
+// exactly as in conv3x3_mfma.h, in the register regime where that scheme is verified (<= 256 VGPRs, no scratch;
+// tools/check_lds_pipeline.py + the bit-identity test against the PIPE = false twin).
+//   KS = 1 (64 -> 128): waves = 2 ci slices x 4 dz slices on the same pixels.
+//   KS = 4 (32 -> 64):  waves = 2 dz slices x 4 k-step groups; each k-step group writes its own partial record.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF, bool PIPE>
+__device__ __forceinline__ u32x2_t lds_tr(unsigned addr) {
+  u32x2_t v;
+  if constexpr (PIPE) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  } else {
+    v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                        (__attribute__((address_space(3))) s16x4_t*)(size_t)(addr + OFF)));
+  }
+  return v;
+}
+
+template <int CIN, int COUT, int SEG, int ROWS, int KS, bool PIPE>
+__global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ a,
+                                                                  float* __restrict__ partial, int B, int H, int W,
+                                                                  int dzs_c, int as_c) {
+  constexpr int CS = COUT / 32, IS = CIN / 32;
+  static_assert(IS * CS * KS == 8, "8 waves = ci slices x dz slices x k-step groups");
+  constexpr int DZS = wg_stride(COUT), AS = wg_stride(CIN);   // bytes per pixel row in LDS
+  constexpr int AW = SEG + 2;
+  constexpr int DZ_BYTES = ROWS * SEG * DZS, A_BYTES = (ROWS + 2) * AW * AS, BUF_BYTES = DZ_BYTES + A_BYTES;
+  constexpr int NDZ = (ROWS * SEG * (COUT / 8) + 511) / 512, NA = ((ROWS + 2) * AW * (CIN / 8) + 511) / 512;
+  constexpr int NKS = ROWS * (SEG / 16) / KS;                // k-steps per wave per item
+  constexpr int PF = 3;                                      // fragments in flight
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int is = wave % IS, cs = (wave / IS) % CS, kg = wave / (IS * CS);
+  const int i16 = lane & 15, qrow = i16 >> 2, pq = i16 & 3, chalf = (lane >> 4) & 1;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned dz_lane = lds0 + (8 * h + qrow) * DZS + (cs * 32 + 16 * chalf + 4 * pq) * 2;
+  const unsigned a_lane = lds0 + DZ_BYTES + (8 * h + qrow) * AS + (is * 32 + 16 * chalf + 4 * pq) * 2;
+
+  f32x16_t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float dbsum = 0.f;
+
+  const int nseg = (W + SEG - 1) / SEG, nrp = (H + ROWS - 1) / ROWS;
+  const long nitems = (long)B * nrp * nseg;
+  uint4 sdz[NDZ], sa[NA];
+  auto load_item = [&](long item) {       // global -> registers (zeros outside the image)
+    const int seg = (int)(item % nseg);
+    const long bt = item / nseg;
+    const int t0 = ROWS * (int)(bt % nrp), b = (int)(bt / nrp);
+    const int f0 = seg * SEG;
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int e = k * 512 + tid;
+      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
+      const bool ok = e < ROWS * SEG * (COUT / 8) && t0 + rr < H && f0 + p < W;
+      const uint4 v = *(const uint4*)(dz + (ok ? (((size_t)b * H + t0 + rr) * W + f0 + p) * dzs_c + cg * 8 : 0));
+      sdz[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int e = k * 512 + tid;
+      const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
+      const int tt = t0 + row - 1, ff = f0 - 1 + sl;
+      const bool ok = e < (ROWS + 2) * AW * (CIN / 8) && tt >= 0 && tt < H && ff >= 0 && ff < W;
+      const uint4 v = *(const uint4*)(a + (ok ? (((size_t)b * H + tt) * W + ff) * as_c + cg * 8 : 0));
+      sa[k] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_item = [&](int buf) {        // registers -> LDS tiles of buffer `buf`
+    char* dzb = smem + buf * BUF_BYTES;
+    char* ab = dzb + DZ_BYTES;
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int e = k * 512 + tid;
+      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
+      if (e < ROWS * SEG * (COUT / 8)) *(uint4*)(dzb + (rr * SEG + p) * DZS + cg * 16) = sdz[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int e = k * 512 + tid;
+      const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
+      if (e < (ROWS + 2) * AW * (CIN / 8)) *(uint4*)(ab + (row * AW + sl) * AS + cg * 16) = sa[k];
+    }
+  };
+
+  // one item: NKS k-steps x (1 dz + 9 activation fragments), pipelined PF fragments deep.  Fragment n of k-step j:
+  // n = 0 -> dz, n = 1..9 -> tap n-1.  The wave's k-steps are kidx = kg*NKS + j (row kidx / (SEG/16), 16-pixel group).
+  auto compute = [&](int buf) {
+    constexpr int NF = 10 * NKS;
+    const unsigned dzb = dz_lane + buf * BUF_BYTES, ab = a_lane + buf * BUF_BYTES;
+    const unsigned kg_dz = (unsigned)(kg * NKS / (SEG / 16) * SEG + (kg * NKS % (SEG / 16)) * 16) * DZS;   // KS > 1: the group's first k-step
+    const unsigned kg_a = (unsigned)(kg * NKS / (SEG / 16) * AW + (kg * NKS % (SEG / 16)) * 16) * AS;
+    u32x2_t f0[PF], f1[PF];
+    uint4 av = make_uint4(0u, 0u, 0u, 0u);
+    auto step = [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      if constexpr (s < NF) {
+        constexpr int j = s / 10, n = s % 10;
+        constexpr int rr = j / (SEG / 16), ks = j % (SEG / 16);     // relative to the group's first k-step (NKS <= SEG/16 or KS == 1)
+        if constexpr (n == 0) {
+          constexpr int off = (rr * SEG + ks * 16) * DZS;
+          f0[s % PF] = lds_tr<off, PIPE>(dzb + kg_dz);
+          f1[s % PF] = lds_tr<off + 4 * DZS, PIPE>(dzb + kg_dz);
+        } else {
+          constexpr int tap = n - 1, dy = tap / 3, dx = tap % 3;
+          constexpr int off = ((rr + dy) * AW + ks * 16 + dx) * AS;
+          f0[s % PF] = lds_tr<off, PIPE>(ab + kg_a);
+          f1[s % PF] = lds_tr<off + 4 * AS, PIPE>(ab + kg_a);
+        }
+      }
+      if constexpr (s >= PF - 1) {
+        constexpr int c = s - (PF - 1);
+        constexpr int n = c % 10;
+        constexpr int young = 2 * ((NF - 1 - c) < (PF - 1) ? (NF - 1 - c) : (PF - 1));
+        if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0[c % PF]), "+v"(f1[c % PF]) : "n"(young));
+        const uint4 fv = make_uint4(f0[c % PF][0], f0[c % PF][1], f1[c % PF][0], f1[c % PF][1]);
+        if constexpr (n == 0) {
+          av = fv;
+          if (is == 0) {
+            const unsigned u[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dbsum += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
+          }
+        } else {
+          acc[n - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, fv),
+                                                               acc[n - 1], 0, 0, 0);
+        }
+      }
+    };
+    static_for(std::make_integer_sequence<int, NF + PF - 1>{}, step);
+  };
+  static_assert(KS == 1 || NKS <= SEG / 16, "a k-step group stays inside one row");
+
+  long item = blockIdx.x;
+  if (item < nitems) { load_item(item); store_item(0); }
+  __syncthreads();
+  for (int n = 0; item < nitems; item += gridDim.x, ++n) {
+    const long next = item + gridDim.x;
+    if (next < nitems) load_item(next);
+    compute(n & 1);
+    if (next < nitems) store_item((n + 1) & 1);
+    __syncthreads();
+  }
+
+  constexpr size_t REC = (size_t)COUT * CIN * 9 + COUT;
+  float* out = partial + ((size_t)blockIdx.x * KS + kg) * REC;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = cs * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, ci = is * 32 + r;
+      out[((size_t)co * CIN + ci) * 9 + tap] = acc[tap][i];
+    }
+  if (is == 0) {
+    const float v = dbsum + __shfl_xor(dbsum, 32, 64);
+    if (h == 0) out[(size_t)COUT * CIN * 9 + cs * 32 + r] = v;
+  }
+}
+
+template <int CIN, int COUT, int SEG, int ROWS, int KS, bool PIPE>
+static hipError_t launch_wgrad_bf16_v3(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
+                                       hipStream_t s, int dzs_c, int as_c) {
+  constexpr int LDS = 2 * (ROWS * SEG * wg_stride(COUT) + (ROWS + 2) * (SEG + 2) * wg_stride(CIN));
+  auto kern = wgrad3x3_bf16_v3_kernel<CIN, COUT, SEG, ROWS, KS, PIPE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), LDS, s, (const bf16_t*)dz, (const bf16_t*)a, partial, B, H, W, dzs_c, as_c);
+  return hipGetLastError();
+}
+
+template <int CIN, int COUT, int SEG, bool KSPLIT>
+static hipError_t launch_wgrad_bf16_v2(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
+                                       hipStream_t s, int dzs_c, int as_c) {
+  constexpr int LDS = 2 * (2 * SEG * wg_stride(COUT) + 4 * (SEG + 2) * wg_stride(CIN));
+  auto kern = wgrad3x3_bf16_v2_kernel<CIN, COUT, SEG, KSPLIT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LDS, s, (const bf16_t*)dz, (const bf16_t*)a, partial, B, H, W, dzs_c, as_c);
+  return hipGetLastError();
+}
+
 template <int CIN, int COUT>
 static hipError_t launch_wgrad_bf16(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
                                     hipStream_t s, int dzs_c, int as_c) {
@@ -270,7 +619,12 @@ static hipError_t launch_wgrad_t(const void* dz, const void* a, float* partial, 
   return hipGetLastError();
 }
 
-// dW [COUT][CIN][3][3] and db [COUT] <- dz [B][H][W][COUT], a [B][H][W][CIN]; partial: nwg * (COUT*CIN*9 + COUT) floats
+static int g_wgrad_variant = 3;   // 3 = asm-pipelined v3 (product), 30 = its compiler-scheduled twin, 2 = v2 (test hooks)
+void set_wgrad_variant(int v) { g_wgrad_variant = v; }
+static int wgrad_variant() { return g_wgrad_variant; }
+
+// dW [COUT][CIN][3][3] and db [COUT] <- dz [B][H][W][COUT], a [B][H][W][CIN]; partial: nwg * (128*64*9 + 256) floats
+// (the bf16 32 -> 64 kernel writes 4 records of 64*32*9 + 64 floats per workgroup)
 hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const void* a, float* partial, float* dw,
                            float* db, int B, int H, int W, int nwg, hipStream_t s) {
   return launch_wgrad3x3_window(prec, cin, cout, cin, cout, 0, 0, dz, a, partial, dw, db, B, H, W, nwg, s);
@@ -286,9 +640,19 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
   const void* dzw = (const char*)dz + (size_t)co_off * es;
   const void* aw = (const char*)a + (size_t)ci_off * es;
   hipError_t e;
+  int nparts = nwg;     // partial records written
   if (prec == DFA_PREC_BF16) {
-    if (cin == 64 && cout == 128) e = launch_wgrad_bf16<64, 128>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
-    else if (cin == 32 && cout == 64) e = launch_wgrad_bf16<32, 64>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+    const int variant = wgrad_variant();
+    if (cin == 64 && cout == 128) {
+      if (variant == 2) e = launch_wgrad_bf16_v2<64, 128, 32, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      else if (variant == 30) e = launch_wgrad_bf16_v3<64, 128, 32, 2, 1, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      else e = launch_wgrad_bf16_v3<64, 128, 32, 2, 1, true>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+    } else if (cin == 32 && cout == 64) {
+      if (variant == 2) e = launch_wgrad_bf16_v2<32, 64, 64, true>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      else if (variant == 30) e = launch_wgrad_bf16_v3<32, 64, 64, 4, 4, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      else e = launch_wgrad_bf16_v3<32, 64, 64, 4, 4, true>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      nparts = 4 * nwg;
+    }
     else return hipErrorInvalidValue;
   } else {
     if (cin == 64 && cout == 128) e = launch_wgrad_t<float, 64, 128>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
@@ -298,9 +662,9 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
   if (e != hipSuccess) return e;
   const int n = cout * cin * 9;
   // weight block: partial record [cout][cin][9] -> dw rows co_off.., columns ci_off.. of [cout_total][cin_total][9]
-  e = launch_reduce_wgrad_window(partial, nwg, n + cout, cin, cout, cin_total, ci_off, co_off, dw, s);
+  e = launch_reduce_wgrad_window(partial, nparts, n + cout, cin, cout, cin_total, ci_off, co_off, dw, s);
   if (e != hipSuccess || !db) return e;
-  return launch_reduce_partials_strided(partial, nwg, n + cout, n, cout, db + co_off, s);
+  return launch_reduce_partials_strided(partial, nparts, n + cout, n, cout, db + co_off, s);
 }
 
 }  // namespace dfa

@@ -111,6 +111,36 @@ def test_train_bf16_mode_and_dropout_run(golden):
     assert not torch.equal(l1, l2)
 
 
+def test_bf16_weight_gradient_kernel_twins_are_bit_identical(golden):
+    """The bf16 weight-gradient kernel (wgrad_mfma.hip v3) reads its transposed LDS fragments through asm-pipelined
+    ds_read_b64_tr_b16; its compiler-scheduled twin runs the same MFMAs in the same order, so every gradient must be
+    bit-identical -- at the golden size and at a batch large enough to wrap the persistent workgroups many times.
+    The earlier 4-wave kernel (v2) sums the same products in another order: fp32-rounding agreement."""
+    from dfa_amd import _lib
+    _, g = golden("cnn2d_train")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(9)
+    cases = [(torch.from_numpy(g["ls0.x"]).transpose(1, 2), torch.from_numpy(g["ls0.y"])),
+             (torch.randn(48, 180, 161, generator=gen).transpose(1, 2), (torch.rand(48, generator=gen) > 0.5).float())]
+
+    def grads(variant, x, y):
+        ctx.set_option("wgrad_variant", variant)
+        model = _fresh_model(g, precision="bf16")
+        loss = torch.nn.BCEWithLogitsLoss()(model(x.to("cuda")).squeeze(-1), y.to("cuda"))
+        loss.backward()
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    try:
+        for x, y in cases:
+            g3, g30, g2 = grads(3, x, y), grads(30, x, y), grads(2, x, y)
+            for n in g3:
+                assert torch.equal(g3[n], g30[n]), n
+                scale = max(float(g3[n].abs().max()), 1e-6)
+                assert float((g3[n] - g2[n]).abs().max()) <= 1e-4 * scale + 1e-7, n
+    finally:
+        ctx.set_option("wgrad_variant", 3)
+
+
 def test_train_cli_end_to_end(tmp_path):
     """python -m dfa_amd.train on synthetic pickles: reference-style step and the native step both learn a separable
     toy task (dev EER falls far below chance) and write reference-format checkpoints that dfa_amd.predict can load."""
