@@ -114,6 +114,34 @@ __global__ void reduce_wgrad_window_kernel(const float* __restrict__ partial, in
   dw[((size_t)(co_off + co) * cin_total + ci_off + ci) * 9 + tap] = (float)s;
 }
 
+// whole weight-gradient record in one launch: elements [0, cout*cin*9) -> the dw window, [cout*cin*9, +cout) -> db.
+// 64 elements x 4 groups of partial records per block; fp64 sums, combined in a fixed order.
+__global__ __launch_bounds__(256) void reduce_wgrad_record_kernel(const float* __restrict__ partial, int nparts, int stride,
+                                                                  int cin, int cout, int cin_total, int ci_off, int co_off,
+                                                                  float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int n = cout * cin * 9, total = n + cout;
+  const int e = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (e < total) {
+    const int k0 = (int)((long)pg * nparts / 4), k1 = (int)((long)(pg + 1) * nparts / 4);
+    const float* p = partial + (size_t)k0 * stride + e;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k, p += stride) s += (double)*p;
+  }
+  red[pg][lane] = s;
+  __syncthreads();
+  if (pg != 0 || e >= total) return;
+  const float v = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (e < n) {
+    const int tap = e % 9, ci = (e / 9) % cin, co = e / (9 * cin);
+    dw[((size_t)(co_off + co) * cin_total + ci_off + ci) * 9 + tap] = v;
+  } else if (db) {
+    db[co_off + e - n] = v;
+  }
+}
+
 // ---- forward: BN(batch stats) + ReLU + AvgPool2d((2,1)) + Dropout        z[B][H][W][C] -> a[B][H/2][W][C]
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_poolh2_drop_kernel(const T* __restrict__ z, const float* __restrict__ mean,
@@ -462,6 +490,14 @@ hipError_t launch_reduce_wgrad_window(const float* partial, int nparts, int stri
   const int n = cout * cin * 9;
   hipLaunchKernelGGL(reduce_wgrad_window_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nparts, stride, cin, cout,
                      cin_total, ci_off, co_off, dw);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
+                                      int ci_off, int co_off, float* dw, float* db, hipStream_t s) {
+  const int total = cout * cin * 9 + cout;
+  hipLaunchKernelGGL(reduce_wgrad_record_kernel, dim3((total + 63) / 64), dim3(256), 0, s, partial, nparts, stride, cin, cout,
+                     cin_total, ci_off, co_off, dw, db);
   return hipGetLastError();
 }
 

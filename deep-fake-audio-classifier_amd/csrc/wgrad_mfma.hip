@@ -662,9 +662,7 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
   if (e != hipSuccess) return e;
   const int n = cout * cin * 9;
   // weight block: partial record [cout][cin][9] -> dw rows co_off.., columns ci_off.. of [cout_total][cin_total][9]
-  e = launch_reduce_wgrad_window(partial, nparts, n + cout, cin, cout, cin_total, ci_off, co_off, dw, s);
-  if (e != hipSuccess || !db) return e;
-  return launch_reduce_partials_strided(partial, nparts, n + cout, n, cout, db + co_off, s);
+  return launch_reduce_wgrad_record(partial, nparts, n + cout, cin, cout, cin_total, ci_off, co_off, dw, db, s);
 }
 
 }  // namespace dfa
