@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   const int H = a.H1, W = a.F, T = a.T;
   const int nb = nsl * 32;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const float rlim = relu_limit();
 
   // ---- register-resident operands: block-2 weight slice (72 VGPRs) and the four block-1 A operands (16 VGPRs)
   uint4 w[9][NKG];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
         if constexpr (c == C_XSTORE) x_store((it + 3) & 1);
         if constexpr (c == S_RELU0) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc0[e] = relu1(acc0[e]);
+          for (int e = 0; e < 16; ++e) acc0[e] = relu1(acc0[e], rlim);
         }
       }
     };
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     const int Ho = H >> 1, to = t0 >> 1;
     float v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = acc0[i] + relu1(acc1[i]);
+    for (int i = 0; i < 16; ++i) v[i] = acc0[i] + relu1(acc1[i], rlim);
     bf16_t* o = a.out + (((size_t)b * Ho + to) * W + col) * 64 + nb;
     const bool ok = (to < Ho) && col_ok;
 #pragma unroll

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   const int cout_base = blockIdx.y * (NSL * 32);
   const char* in_b = (const char*)a.in + (size_t)b * H * W * PB;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const float rlim = relu_limit();
 
   // ---- weights [tap][kk][ca]: 36 fragments = 144 VGPRs for the kernel's lifetime
   uint4 w[9][2][2];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
             for (int pb2 = 0; pb2 < 2; ++pb2)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc0[ca][pb2][e] = relu1(acc0[ca][pb2][e]);
+              for (int e = 0; e < 4; ++e) acc0[ca][pb2][e] = relu1(acc0[ca][pb2][e], rlim);
         }
       }
     };
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) cs[ca][pb][e] += acc0[ca][pb][e] + relu1(acc1[ca][pb][e]);
+          for (int e = 0; e < 4; ++e) cs[ca][pb][e] += acc0[ca][pb][e] + relu1(acc1[ca][pb][e], rlim);
     } else if (t0 < H) {
 #pragma unroll
       for (int ca = 0; ca < 2; ++ca)

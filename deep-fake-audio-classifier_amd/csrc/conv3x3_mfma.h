@@ -77,9 +77,15 @@ __device__ __forceinline__ float cvt_out<float>(float f) { return f; }
 template <>
 __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float f) { return float_to_bf16(f); }
 
-// ReLU as ONE instruction (v_med3_f32 x, 0, +inf).  fmaxf() costs two: the compiler canonicalises the operand first.
-// Not inline asm: the compiler's MFMA -> VALU hazard nops do not cover asm statements.
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// ReLU as ONE instruction: v_med3_f32(x, 0, lim) with lim = +inf held in an SGPR the compiler cannot see through
+// (relu_limit()).  fmaxf(x, 0) costs two -- the compiler canonicalises the operand first -- and so does a med3 against a
+// literal +inf, which it folds back into that max.  Not inline asm either: the MFMA -> VALU hazard nops do not cover asm.
+__device__ __forceinline__ float relu_limit() {
+  float lim = __builtin_inff();
+  asm volatile("" : "+s"(lim));
+  return lim;
+}
+__device__ __forceinline__ float relu1(float x, float lim) { return __builtin_amdgcn_fmed3f(x, 0.f, lim); }
 
 enum { EPI_POOL_H2 = 0, EPI_POOL_2X2 = 1, EPI_MEAN_T = 2, EPI_PLAIN = 3, EPI_RAW = 4 };
 
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       for (int kg = 0; kg < NKG; ++kg) w[tap][kg] = wp[(tap * NKG + kg) * 64];
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
+  const float rlim = relu_limit();
   // PFD > 0: asm-pipelined fragment reads, PFD reads in flight; 0: compiler-scheduled reads; -1: pipelined (depth 4) for
   // the two-waves-per-SIMD bf16 kernels.  The one-wave-per-SIMD kernels keep weights in AGPRs and spill; there the
   // compiler-scheduled form is used (an fp32 ACCIN kernel produced wrong sums with pipelined reads under that register
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         if constexpr (i >= 1) acc1 = Mma<T>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
         if constexpr (EARLY_RELU && c == S_RELU0) {   // rows 0..2 of acc0 are complete: its ReLU hides under acc1's last MFMAs
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc0[e] = relu1(acc0[e]);
+          for (int e = 0; e < 16; ++e) acc0[e] = relu1(acc0[e], rlim);
         }
       }
     };
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       const int Ho = H >> 1, to = t0 >> 1;
       float v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = (EARLY_RELU ? acc0[i] : relu1(acc0[i])) + relu1(acc1[i]);   // 1/2 is in the weights
+      for (int i = 0; i < 16; ++i) v[i] = (EARLY_RELU ? acc0[i] : relu1(acc0[i], rlim)) + relu1(acc1[i], rlim);   // 1/2 is in the weights
       T* o = (T*)a.out + (((size_t)b * Ho + to) * W + col) * COUT + nb;
       const bool ok = (to < Ho) && col_ok;
       if (sizeof(T) == 4) {
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       float v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float s = (EARLY_RELU ? acc0[i] : relu1(acc0[i])) + relu1(acc1[i]);      // 1/4 is in the weights
+        const float s = (EARLY_RELU ? acc0[i] : relu1(acc0[i], rlim)) + relu1(acc1[i], rlim);      // 1/4 is in the weights
         v[i] = s + __shfl_xor(s, 1, 64);                                  // + the neighbouring column (lane r ^ 1)
       }
       const int fo = col >> 1;
@@ -441,10 +448,10 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
     } else if (EPI == EPI_MEAN_T) {
       if (t0 + 1 < H) {          // wave-uniform: only the last row pair of an odd H takes the other branch
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cs[i] += (EARLY_RELU ? acc0[i] : relu1(acc0[i])) + relu1(acc1[i]);
+        for (int i = 0; i < 16; ++i) cs[i] += (EARLY_RELU ? acc0[i] : relu1(acc0[i], rlim)) + relu1(acc1[i], rlim);
       } else if (t0 < H) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cs[i] += (EARLY_RELU ? acc0[i] : relu1(acc0[i]));
+        for (int i = 0; i < 16; ++i) cs[i] += (EARLY_RELU ? acc0[i] : relu1(acc0[i], rlim));
       }
     } else if (EPI == EPI_RAW) {
       float* o0 = a.raw_out + (((size_t)b * H + t0) * W + col) * COUT + nb + 4 * h;
@@ -461,8 +468,8 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       float v0[16], v1[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        v0[i] = a.relu ? relu1(acc0[i]) : acc0[i];
-        v1[i] = a.relu ? relu1(acc1[i]) : acc1[i];
+        v0[i] = a.relu ? relu1(acc0[i], rlim) : acc0[i];
+        v1[i] = a.relu ? relu1(acc1[i], rlim) : acc1[i];
       }
       if (STATS) {
         const float m0 = r0ok ? 1.f : 0.f, m1 = r1ok ? 1.f : 0.f;
