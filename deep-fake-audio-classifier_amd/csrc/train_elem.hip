@@ -396,27 +396,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, const float* __restrict__ sums,
                                                            const float* __restrict__ demb, const T* __restrict__ da,
                                                            T* __restrict__ dz, int B, int H, int W, int C, DropCfg dc,
-                                                           float inv_n) {
-  const int CG = C >> 3;
-  const size_t total = (size_t)B * H * W * CG;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int cg = (int)(i % CG);
-  const size_t p = i / CG;
-  const int f = (int)(p % W);
-  const size_t bt_ = p / W;
-  const int t = (int)(bt_ % H), b = (int)(bt_ / H);
-  float v[8], g[8], o[8];
-  ld8<T>(z + p * C + cg * 8, v);
-  upstream8<T, SRC>(demb, da, dc, b, t, f, cg, H, W, C, 1.0f / (float)H, g);
+                                                           float inv_n, int pix_per_block) {
+  // thread = (channel octet cg, pixel lane pl): the per-channel coefficients are loaded once and reused over the block's
+  // pixels (one thread per 16-byte chunk spent 48 parameter loads on every data load)
+  const int CG = C >> 3, PL = 256 / CG;
+  const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+  const size_t npix = (size_t)B * H * W;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+  float mu[8], is[8], gm[8], bt[8], k0[8], k1[8], k2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    const float xh = (v[j] - mean[c]) * invstd[c];
-    const float dy = (fmaf(gamma[c], xh, beta[c]) > 0.f) ? g[j] : 0.f;
-    o[j] = gamma[c] * invstd[c] * (dy - sums[2 * c] * inv_n - xh * sums[2 * c + 1] * inv_n);
+    mu[j] = mean[c]; is[j] = invstd[c]; gm[j] = gamma[c]; bt[j] = beta[c];
+    k0[j] = gm[j] * is[j];
+    k1[j] = sums[2 * c] * inv_n;
+    k2[j] = sums[2 * c + 1] * inv_n;
   }
-  st8<T>(dz + p * C + cg * 8, o);
+  const float inv_h = 1.0f / (float)H;
+#pragma unroll 4
+  for (size_t p = p0 + pl; p < p1; p += PL) {
+    const int f = (int)(p % W);
+    const size_t bt_ = p / W;
+    const int t = (int)(bt_ % H), b = (int)(bt_ / H);
+    float v[8], g[8], o[8];
+    ld8<T>(z + p * C + cg * 8, v);
+    upstream8<T, SRC>(demb, da, dc, b, t, f, cg, H, W, C, inv_h, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mu[j]) * is[j];
+      const float dy = (fmaf(gm[j], xh, bt[j]) > 0.f) ? g[j] : 0.f;
+      o[j] = k0[j] * (dy - k1[j] - xh * k2[j]);
+    }
+    st8<T>(dz + p * C + cg * 8, o);
+  }
 }
 
 // ---- loss: BCEWithLogitsLoss(mean) on smoothed labels (src/train.py:311-320) + its gradient
@@ -577,8 +590,8 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
   const int nblk = bn_bwd_blocks(B, H, W, &ppb);
   const int PL = 256 / (C / 8);
   const size_t lds = (size_t)PL * C * 2 * sizeof(float);
-  const size_t total = (size_t)B * H * W * (C / 8);
-  dim3 g2((unsigned)((total + 255) / 256));
+  const int ppb2 = 16 * PL;                       // pixels per block of the apply pass: 16 chunks per thread
+  dim3 g2((unsigned)(((size_t)B * H * W + ppb2 - 1) / ppb2));
   const float inv_n = (float)(1.0 / ((double)B * H * W));
 #define DFA_BN_BWD(TT, SRC)                                                                                            \
   do {                                                                                                                 \
@@ -590,7 +603,7 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
     if (e != hipSuccess) return e;                                                                                     \
     if (dz)                                                                                                            \
       hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \
-                         demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n);                                        \
+                         demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n, ppb2);                                        \
   } while (0)
   if (prec == DFA_PREC_BF16) {
     if (src == SRC_MEANT) DFA_BN_BWD(bf16_t, SRC_MEANT);
