@@ -62,9 +62,16 @@ int dfa_version(void);
 int dfa_ctx_create(int device_id, void* hip_stream, dfa_ctx** out);
 int dfa_ctx_destroy(dfa_ctx* ctx);
 int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
-/* tuning switches; "conv_dma" = 1 stages the MFMA convolutions' input rows with LDS-DMA (global_load_lds) instead of
- * through registers, 0 forces register staging, -1 (default) picks per kernel (also settable with the environment
- * variable DFA_CONV_DMA=0|1 before dfa_ctx_create) */
+/* tuning / test switches (all default to the fastest verified path; the alternatives exist so the tests can compare):
+ *   "conv_dma"      1 = stage the MFMA convolutions' input rows with LDS-DMA (global_load_lds), 0 = through registers,
+ *                   -1 (default) = per-kernel choice (also: environment variable DFA_CONV_DMA=0|1 before dfa_ctx_create)
+ *   "lds_pipe"      1 (default) = asm-pipelined LDS fragment reads in the bf16 kernels that have them, 0 = their
+ *                   compiler-scheduled twins (bit-identical results)
+ *   "fuse_conv1"    1 (default) = CNN2D bf16 mode on bf16 features runs blocks 1+2 as one kernel, 0 = two kernels
+ *   "block3_m16"    1 (default) = CNN2D bf16 block 3 on v_mfma_f32_16x16x32_bf16, 0 = the 32x32x16 kernel
+ *   "wgrad_variant" 3 (default) = pipelined bf16 weight-gradient kernel, 30 = its compiler-scheduled twin, 2 = the
+ *                   earlier 4-wave kernel (process-wide)
+ * unknown names return DFA_E_UNSUPPORTED */
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value);
 const char* dfa_last_error(const dfa_ctx* ctx);
 const char* dfa_error_name(int code);
