@@ -27,20 +27,27 @@ struct DropCfg {
   unsigned layer;
 };
 
-// keep-scale factors (0 or scale) of 8 consecutive elements starting at idx (idx % 8 == 0)
+// keep-scale factors (0 or scale) of 8 consecutive elements starting at idx (idx % 8 == 0).  ONE Philox call per 8
+// elements: each 32-bit output word gives two 16-bit uniforms, compared with the top 16 bits of the threshold (the drop
+// probability is quantised to 1/65536 -- the mask stream of the reference's generator cannot be reproduced anyway, parity
+// with dropout > 0 is statistical).  The Philox rounds are quarter-rate integer multiplies: with two calls per 16-byte
+// chunk the elementwise dropout passes were RNG-bound at ~1.2 TB/s.
 __device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, float* f) {
   if (d.thresh == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = 1.f;
     return;
   }
-  const uint64_t q = (idx >> 2) + d.offset;
+  const uint64_t q = (idx >> 3) + d.offset;
   const uint2 key = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
   const uint4 r0 = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
-  const uint4 r1 = philox4x32_10(make_uint4((unsigned)(q + 1), (unsigned)((q + 1) >> 32), d.layer, 0u), key);
-  const unsigned r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  const unsigned t16 = d.thresh >> 16;
+  const unsigned r[4] = {r0.x, r0.y, r0.z, r0.w};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = (r[j] < d.thresh) ? 0.f : d.scale;
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = ((r[j] & 0xffffu) < t16) ? 0.f : d.scale;
+    f[2 * j + 1] = ((r[j] >> 16) < t16) ? 0.f : d.scale;
+  }
 }
 
 }  // namespace dfa

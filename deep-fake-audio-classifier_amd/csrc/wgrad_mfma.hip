@@ -128,119 +128,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(const T* __restri
 // per lane for one channel, i.e. a column of the channels-last LDS tile: ds_read_b64_tr_b16 delivers exactly that (a
 // 4-pixel x 16-channel block transposed per 16-lane group), and because a pixel is a ROW of the tile the 3x3 tap shift
 // is a plain row offset -- no unaligned accesses.  Pixel rows are padded to a stride == 64 (mod 128) bytes so the 4
-// rows x 64 bytes a half-wave touches fall on disjoint bank windows (conflict-free).  Work item = 2 output rows x 64
-// columns: dz tile 2 x 64 pixels, activation tile 4 x 66 pixels.
+// rows x 64 bytes a half-wave touches fall on disjoint bank windows (conflict-free).
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 constexpr int wg_stride(int c) { return (c * 2 % 128 == 64) ? c * 2 : c * 2 + 64; }
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256, 1) void wgrad3x3_bf16_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ a,
-                                                               float* __restrict__ partial, int B, int H, int W,
-                                                               int dzs_c, int as_c) {
-  constexpr int CS = COUT / 32, IS = CIN / 32;
-  static_assert(CS == 4 || CS == 2, "COUT must be 64 or 128");
-  constexpr int NTAP = (CS == 4) ? 9 : 5;
-  constexpr int NTILE = IS * NTAP;
-  constexpr int DZS = wg_stride(COUT), AS = wg_stride(CIN);   // bytes per pixel row in LDS
-  constexpr int AW = WG_SEG + 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* dzs = smem;                          // [2][WG_SEG] pixels x DZS bytes
-  char* as = smem + 2 * WG_SEG * DZS;        // [4][AW] pixels x AS bytes
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int cs = (CS == 4) ? wave : (wave & 1);
-  const int tap0 = (CS == 4) ? 0 : ((wave >> 1) ? 5 : 0);
-  const int ntap = (CS == 4) ? 9 : ((wave >> 1) ? 4 : 5);
-  // transposed-read lane geometry: group = lane>>4 (h = group>>1, channel half = group&1), q = row of the 4x16 block,
-  // p = 4-column quad the lane supplies the address of; the lane RECEIVES channel 16*(group&1) + (lane&15) = lane&31.
-  const int i16 = lane & 15, qrow = i16 >> 2, pq = i16 & 3, chalf = (lane >> 4) & 1;
-  const int dz_lane = (8 * h + qrow) * DZS + (cs * 32 + 16 * chalf + 4 * pq) * 2;
-  const int a_lane = (8 * h + qrow) * AS + (16 * chalf + 4 * pq) * 2;
-
-  f32x16_t acc[NTILE];
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  float dbsum = 0.f;
-
-  const int nseg = (W + WG_SEG - 1) / WG_SEG, nrp = (H + 1) / 2;
-  const long nitems = (long)B * nrp * nseg;
-  for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int seg = (int)(item % nseg);
-    const long bt = item / nseg;
-    const int t0 = 2 * (int)(bt % nrp), b = (int)(bt / nrp);
-    const int f0 = seg * WG_SEG;
-    __syncthreads();
-    for (int e = tid; e < 2 * WG_SEG * (COUT / 8); e += 256) {
-      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % WG_SEG, rr = e / ((COUT / 8) * WG_SEG);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (t0 + rr < H && f0 + p < W) v = *(const uint4*)(dz + ((((size_t)b * H + t0 + rr) * W + f0 + p) * dzs_c + cg * 8));
-      *(uint4*)(dzs + (rr * WG_SEG + p) * DZS + cg * 16) = v;
-    }
-    for (int e = tid; e < 4 * AW * (CIN / 8); e += 256) {
-      const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
-      const int tt = t0 + row - 1, ff = f0 - 1 + sl;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (tt >= 0 && tt < H && ff >= 0 && ff < W) v = *(const uint4*)(a + ((((size_t)b * H + tt) * W + ff) * as_c + cg * 8));
-      *(uint4*)(as + (row * AW + sl) * AS + cg * 16) = v;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-#pragma unroll 1
-      for (int ks = 0; ks < WG_SEG / 16; ++ks) {
-        const char* dp = dzs + (rr * WG_SEG + ks * 16) * DZS + dz_lane;
-        const s16x4_t d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(dp));
-        const s16x4_t d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(dp + 4 * DZS));
-        const uint2 u0 = __builtin_bit_cast(uint2, d0), u1 = __builtin_bit_cast(uint2, d1);
-        const uint4 av = make_uint4(u0.x, u0.y, u1.x, u1.y);
-        dbsum += (__uint_as_float(u0.x << 16) + __uint_as_float(u0.x & 0xffff0000u)) +
-                 (__uint_as_float(u0.y << 16) + __uint_as_float(u0.y & 0xffff0000u)) +
-                 (__uint_as_float(u1.x << 16) + __uint_as_float(u1.x & 0xffff0000u)) +
-                 (__uint_as_float(u1.y << 16) + __uint_as_float(u1.y & 0xffff0000u));
-#pragma unroll
-        for (int tp = 0; tp < NTAP; ++tp) {
-          if (tp < ntap) {
-            const int tap = tap0 + tp;
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const char* ap = as + ((rr + dy) * AW + ks * 16 + dx) * AS + a_lane;
-#pragma unroll
-            for (int is = 0; is < IS; ++is) {
-              const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ap + is * 64));
-              const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ap + is * 64 + 4 * AS));
-              const uint2 w0 = __builtin_bit_cast(uint2, b0), w1 = __builtin_bit_cast(uint2, b1);
-              const uint4 bv = make_uint4(w0.x, w0.y, w1.x, w1.y);
-              acc[tp * IS + is] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
-                                                                          __builtin_bit_cast(bf16x8_t, bv),
-                                                                          acc[tp * IS + is], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-  }
-  float* out = partial + (size_t)blockIdx.x * ((size_t)COUT * CIN * 9 + COUT);
-#pragma unroll
-  for (int tp = 0; tp < NTAP; ++tp) {
-    if (tp < ntap) {
-      const int tap = tap0 + tp;
-#pragma unroll
-      for (int is = 0; is < IS; ++is)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int co = cs * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, ci = is * 32 + r;
-          out[((size_t)co * CIN + ci) * 9 + tap] = acc[tp * IS + is][i];
-        }
-    }
-  }
-  dbsum += __shfl_xor(dbsum, 32, 64);
-  if (h == 0 && tap0 == 0) out[(size_t)COUT * CIN * 9 + cs * 32 + r] = dbsum;
-}
-
-// ---- bf16 kernel, second version.  The first one gave every wave ONE 32-channel dz slice: each transposed activation
+// ---- bf16 kernel, second version (kept as the reference the tests compare v3 against).  The first one (removed) gave
+// every wave ONE 32-channel dz slice: each transposed activation
 // fragment (2 x ds_read_b64_tr_b16) fed a single MFMA, LDS reads were waited for one by one at one wave per SIMD, and the
 // tiles were staged synchronously: 0.29 PFLOP/s.  Here a wave owns 18 accumulator tiles = 9 taps x 2 dz slices (288
 // AGPRs at one wave per SIMD): a k-step of 16 pixels reads 2 dz + 9 activation fragments for 18 MFMAs (0.6 fragment
@@ -579,21 +473,6 @@ static hipError_t launch_wgrad_bf16_v2(const void* dz, const void* a, float* par
                                        hipStream_t s, int dzs_c, int as_c) {
   constexpr int LDS = 2 * (2 * SEG * wg_stride(COUT) + 4 * (SEG + 2) * wg_stride(CIN));
   auto kern = wgrad3x3_bf16_v2_kernel<CIN, COUT, SEG, KSPLIT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LDS, s, (const bf16_t*)dz, (const bf16_t*)a, partial, B, H, W, dzs_c, as_c);
-  return hipGetLastError();
-}
-
-template <int CIN, int COUT>
-static hipError_t launch_wgrad_bf16(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
-                                    hipStream_t s, int dzs_c, int as_c) {
-  constexpr int LDS = 2 * WG_SEG * wg_stride(COUT) + 4 * (WG_SEG + 2) * wg_stride(CIN);
-  auto kern = wgrad3x3_bf16_kernel<CIN, COUT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
