@@ -6,8 +6,17 @@
 
 namespace dfa {
 
+// The bf16 kernels that fit two waves per SIMD without scratch run with asm-pipelined LDS reads (conv3x3_mfma.h); variant
+// 0 selects their compiler-scheduled twins (bit-identical; GPU test), 1 the earlier one-wave-per-SIMD instantiations.
+static int g_train_conv_variant = 2;
+void set_train_conv_variant(int v) { g_train_conv_variant = v; }
+
 hipError_t launch_train_fwd2(int prec, const ConvArgs& a, hipStream_t s) {
-  if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 1, false, false, true>(a, s);
+  if (prec == DFA_PREC_BF16) {
+    if (g_train_conv_variant == 2) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 2, false, true, true, 4>(a, s);
+    if (g_train_conv_variant == 0) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 2, false, true, true, 0>(a, s);
+    return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 1, false, false, true>(a, s);
+  }
   return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_PLAIN, 1, false, false, true>(a, s);
 }
 
@@ -25,7 +34,9 @@ hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipS
     p1.in_pix_bytes = 128 * 2;
     p1.in_ch_off_bytes = 0;
     p1.raw_out = raw_tmp;
-    hipError_t e = launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_RAW, 1, false, true>(p1, s);
+    hipError_t e = g_train_conv_variant == 2   ? launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_RAW, 2, false, true, false, 3>(p1, s)
+                   : g_train_conv_variant == 0 ? launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_RAW, 2, false, true, false, 0>(p1, s)
+                                               : launch_conv3x3<bf16_t, 64, 2, 2, 2, 1, EPI_RAW, 1, false, true>(p1, s);
     if (e != hipSuccess) return e;
     ConvArgs p2 = a;
     p2.in_pix_bytes = 128 * 2;

@@ -71,6 +71,8 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *   "block3_m16"    1 (default) = CNN2D bf16 block 3 on v_mfma_f32_16x16x32_bf16, 0 = the 32x32x16 kernel
  *   "wgrad_variant" 3 (default) = pipelined bf16 weight-gradient kernel, 30 = its compiler-scheduled twin, 2 = the
  *                   earlier 4-wave kernel (process-wide)
+ *   "train_conv_variant" 2 (default) = pipelined two-wave bf16 training convolutions where they fit, 0 = their
+ *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
  * unknown names return DFA_E_UNSUPPORTED */
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value);
 const char* dfa_last_error(const dfa_ctx* ctx);

@@ -207,7 +207,8 @@ def test_pipelined_lds_reads_are_never_touched_in_flight():
         pytest.skip("hipcc not available")
     csrc = os.path.join(root, "deep-fake-audio-classifier_amd", "csrc")
     total = 0
-    for name in ("conv3x3_inst_cnn2d.hip", "conv3x3_inst_cae.hip", "conv12_fused.hip", "conv3_m16.hip", "wgrad_mfma.hip"):
+    for name in ("conv3x3_inst_cnn2d.hip", "conv3x3_inst_cae.hip", "conv12_fused.hip", "conv3_m16.hip", "wgrad_mfma.hip",
+                 "conv3x3_inst_train.hip"):
         kernels, nreads, violations = chk.check_asm(chk.compile_to_asm(os.path.join(csrc, name)))
         assert not violations, violations[:5]
         total += nreads

@@ -137,8 +137,15 @@ def test_bf16_weight_gradient_kernel_twins_are_bit_identical(golden):
                 assert torch.equal(g3[n], g30[n]), n
                 scale = max(float(g3[n].abs().max()), 1e-6)
                 assert float((g3[n] - g2[n]).abs().max()) <= 1e-4 * scale + 1e-7, n
+            # the pipelined two-wave forward-2 / data-gradient-3 convolutions against their compiler-scheduled twins
+            ctx.set_option("train_conv_variant", 0)
+            t0 = grads(3, x, y)
+            ctx.set_option("train_conv_variant", 2)
+            for n in g3:
+                assert torch.equal(g3[n], t0[n]), n
     finally:
         ctx.set_option("wgrad_variant", 3)
+        ctx.set_option("train_conv_variant", 2)
 
 
 def test_train_cli_end_to_end(tmp_path):
