@@ -112,6 +112,8 @@ def test_cnn2d_fused_blocks_1_2_match_two_kernel_path_and_oracle(golden):
     cases = [("t321", torch.from_numpy(g["t321.x_stored"]), True), ("t7", torch.from_numpy(g["t7.x_stored"]), True),
              ("btf", torch.randn(3, 50, 180, generator=gen), False), ("F65", torch.randn(2, 65, 33, generator=gen), True),
              ("F40", torch.randn(2, 40, 18, generator=gen), True), ("T4", torch.randn(2, 180, 4, generator=gen), True),
+             ("F31", torch.randn(1, 31, 9, generator=gen), True), ("F29", torch.randn(3, 29, 10, generator=gen), True),
+             ("F61T5", torch.randn(2, 5, 61, generator=gen), False), ("F30", torch.randn(1, 30, 322, generator=gen), True),
              ("b64", torch.randn(64, 180, 321, generator=gen) * 3, True)]
     try:
         for name, stored, is_bft in cases:
