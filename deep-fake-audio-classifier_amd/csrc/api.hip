@@ -273,11 +273,12 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   void* a2 = ws + pl.a2_off;
   float* emb = embedding ? embedding : (float*)(ws + pl.emb_off);
   hipStream_t s = ctx->stream;
-  // bf16 mode on bf16 features: blocks 1 and 2 run as one kernel and a1 stays on chip (timing slot 1)
-  const bool fused12 = prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && ctx->fuse_conv1;
+  // bf16 mode: blocks 1 and 2 run as one kernel and a1 stays on chip (timing slot 1); fp32 features are rounded to bf16
+  // as the kernel loads them (bf16 storage mode), exactly like a caller-side .to(bfloat16)
+  const bool fused12 = prec == DFA_PREC_BF16 && ctx->fuse_conv1;
   if (fused12) {
     ScopedSlot ts(ctx, 1);
-    DFA_HIP_CHECK(ctx, launch_conv12_fused(x, stride_b, stride_t, stride_f, m.c1pack, m.c1bias, m.c2.wpack, m.c2.bias, a2,
+    DFA_HIP_CHECK(ctx, launch_conv12_fused(x, x_dtype, stride_b, stride_t, stride_f, m.c1pack, m.c1bias, m.c2.wpack, m.c2.bias, a2,
                                            B, T, F, s));
   } else {
     ScopedSlot ts(ctx, 0);

@@ -1,4 +1,4 @@
-// conv12_fused.hip -- CNN2D blocks 1 and 2 in ONE kernel (bf16 mode, bf16 input):
+// conv12_fused.hip -- CNN2D blocks 1 and 2 in ONE kernel (bf16 mode; fp32 features are rounded to bf16 as they are loaded):
 //   Conv2d(1,32,3,p=1)+BN+ReLU+AvgPool(2,1)  ->  Conv2d(32,64,3,p=1)+BN+ReLU+AvgPool(2,1)      (src/model.py:15-25)
 // The block-1 activation a1 [B,160,180,32] (1.84 MB per utterance, written and re-read through HBM by the two-kernel
 // path: 0.94 GB per step at B = 256) never leaves the chip: the workgroup that consumes a ring block of a1 rows
@@ -26,7 +26,7 @@
 namespace dfa {
 
 struct Conv12Args {
-  const bf16_t* x;          // features, element strides below (any layout)
+  const void* x;            // features (bf16 or fp32: template argument TX), element strides below (any layout)
   long long sxb, sxt, sxf;
   const uint4* c1pack;      // [4][64] A operands: even-hi, even-lo, odd-hi, odd-lo (pack.hip: pack_conv1_mfma_kernel)
   const float* c1bias;      // [32]  0.5 * folded bias
@@ -35,6 +35,9 @@ struct Conv12Args {
   bf16_t* out;              // a2 [B][H1/2][F][64]
   int B, T, F, H1, nstrips;
 };
+
+__device__ __forceinline__ float ld_as_float(const float* p) { return *p; }
+__device__ __forceinline__ float ld_as_float(const bf16_t* p) { return bf16_to_float(*p); }
 
 namespace c12 {
 constexpr int PB = 64, SP = 36, ROWB = SP * PB, BR = 4, NKG = 2, PF = 4, SW = 30;   // SW: output columns per strip
@@ -52,6 +55,7 @@ constexpr int NXLD = (NX + 255) / 256;
 static __device__ long long g_diag12[2048 * 4 * 8];
 #endif
 
+template <typename TX>
 __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   using namespace c12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     xrow[k] = t_fast ? e % XROWS : e / XCOLS;
     xcol[k] = t_fast ? e / XROWS : e % XCOLS;
   }
-  const bf16_t* xb = a.x + (long long)b * a.sxb;
+  const TX* xb = (const TX*)a.x + (long long)b * a.sxb;
   unsigned short xreg[NXLD];   // raw loaded bits; out-of-image elements are zeroed when they are stored, not here: a
   bool xok[NXLD];              // select on the loaded value would make the wave wait out the load latency at issue time
   auto x_load = [&](int j) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     for (int k = 0; k < NXLD; ++k) {
       const int t = 8 * j - 3 + xrow[k], f = f0 - 2 + xcol[k];
       xok[k] = (k * 256 + tid < NX) && t >= 0 && t < T && f >= 0 && f < W;
-      xreg[k] = xb[xok[k] ? (long long)t * a.sxt + (long long)f * a.sxf : 0].v;   // clamped address, branch-free
+      xreg[k] = cvt_out<bf16_t>(ld_as_float(xb + (xok[k] ? (long long)t * a.sxt + (long long)f * a.sxf : 0))).v;   // clamped address, branch-free
     }
   };
   auto x_store = [&](int buf) {   // element (row, c) is tap e of the windows of slots c - e, e = 0..2
@@ -331,21 +335,26 @@ hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pac
   return hipGetLastError();
 }
 
-hipError_t launch_conv12_fused(const void* x, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack,
+hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack,
                                const float* c1bias, const uint4* wpack2, const float* bias2, void* a2, int B, int T,
                                int F, hipStream_t s) {
   Conv12Args a{};
-  a.x = (const bf16_t*)x; a.sxb = sb; a.sxt = st; a.sxf = sf;
+  a.x = x; a.sxb = sb; a.sxt = st; a.sxf = sf;
   a.c1pack = c1pack; a.c1bias = c1bias; a.wpack = wpack2; a.bias = bias2; a.out = (bf16_t*)a2;
   a.B = B; a.T = T; a.F = F; a.H1 = T / 2; a.nstrips = (F + c12::SW - 1) / c12::SW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv12_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)conv12_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        c12::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv12_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, c12::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv12_fused_kernel, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
+  if (x_dtype == DFA_DTYPE_BF16)
+    hipLaunchKernelGGL(conv12_fused_kernel<bf16_t>, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL(conv12_fused_kernel<float>, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
 #ifdef DFA_STAMPS
   {
     static int calls = 0;

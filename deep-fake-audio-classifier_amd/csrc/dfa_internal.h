@@ -89,7 +89,7 @@ struct dfa_ctx {
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
   int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
-  int fuse_conv1 = 1;          // bf16 mode + bf16 input: blocks 1 and 2 in one kernel (conv12_fused.hip); 0 = two kernels
+  int fuse_conv1 = 1;          // bf16 mode: blocks 1 and 2 in one kernel (conv12_fused.hip; fp32 features are rounded to bf16 on load); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
@@ -250,7 +250,7 @@ hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stri
 void set_train_conv_variant(int v);   // conv3x3_inst_train.hip (process-wide test hook)
 void set_wgrad_variant(int v);   // wgrad_mfma.hip: bf16 weight-gradient kernel selection (process-wide test hook)
 hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pack, float* c1bias, hipStream_t s);
-hipError_t launch_conv12_fused(const void* x, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack, const float* c1bias,
+hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack, const float* c1bias,
                                const uint4* wpack2, const float* bias2, void* a2, int B, int T, int F, hipStream_t s);
 hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
