@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import distributed as dfa_dist
-from .augmentation import channel_drop, compose, gaussian_jitter, spec_augment, time_shift
+from .augmentation import FusedAugment, channel_drop, compose, gaussian_jitter, spec_augment, time_shift
 from .dataloaders import FlatBatcher, make_loader
 from .dataset import AudioDeepfakeDataset
 from .evaluation import evaluate
@@ -75,7 +75,14 @@ def train_one_epoch_native(trainer, batcher, augment_fn=None, swap_tf: bool = Tr
     return (float(total.item()) / count) if count else None
 
 
-def build_augment_fn(args):
+def build_augment_fn(args, fused: bool = False):
+    """fused = True (GPU training): the whole pipeline as one HIP pass (augmentation.FusedAugment), same parameter draws."""
+    if fused and (args.spec_augment or args.time_shift or args.channel_drop or args.gaussian_jitter):
+        return FusedAugment(spec_augment=args.spec_augment, time_mask_ratio=args.time_mask_ratio,
+                            feature_mask=args.feature_mask, feature_mask_ratio=args.feature_mask_ratio,
+                            time_shift=args.time_shift, time_shift_ratio=args.time_shift_ratio,
+                            channel_drop=args.channel_drop, channel_drop_prob=args.channel_drop_prob,
+                            gaussian_jitter=args.gaussian_jitter, gaussian_jitter_std=args.gaussian_jitter_std)
     fns = []
     if args.spec_augment:
         fns.append(lambda x: spec_augment(x, time_mask_ratio=args.time_mask_ratio,
@@ -174,7 +181,7 @@ def main(argv=None):
         model = CNN2D(in_features=args.in_features, dropout=args.dropout, precision=args.precision).to(device)
     weight_decay = args.weight_decay if args.weight_decay > 0 else 0.01      # AdamW default of src/train.py:321-325
     criterion = make_criterion(args.label_smoothing)
-    augment_fn = build_augment_fn(args)
+    augment_fn = build_augment_fn(args, fused=(device.type == "cuda"))   # batches are on the GPU when it is applied
 
     if args.native or world > 1:
         from .training.train_step import NativeTrainer

@@ -1,0 +1,64 @@
+"""GPU tests of the fused augmentation pass (dfa_augment_batch) against the op-by-op pipeline it replaces."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_pipeline(x, cfg):
+    """the torch-op composition train.build_augment_fn builds (reference order, src/train.py:271-289)"""
+    from dfa_amd import augmentation as A
+    if cfg["spec_augment"]:
+        x = A.spec_augment(x, time_mask_ratio=cfg["time_mask_ratio"], feature_mask_ratio=cfg["feature_mask_ratio"],
+                           apply_time_mask=True, apply_feature_mask=cfg["feature_mask"])
+    if cfg["time_shift"]:
+        x = A.time_shift(x, max_shift_ratio=cfg["time_shift_ratio"])
+    if cfg["channel_drop"]:
+        x = A.channel_drop(x, drop_prob=cfg["channel_drop_prob"])
+    return x
+
+
+@pytest.mark.parametrize("layout", ["btf", "bft_view"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_augment_equals_op_by_op_pipeline(layout, dtype):
+    """Same seeds -> same spans, shift and keep mask -> bit-identical batch (every op is a select / exact multiply)."""
+    from dfa_amd.augmentation import FusedAugment
+    cfgs = [dict(spec_augment=True, time_mask_ratio=0.2, feature_mask=True, feature_mask_ratio=0.1, time_shift=True,
+                 time_shift_ratio=0.1, channel_drop=True, channel_drop_prob=0.3),
+            dict(spec_augment=True, time_mask_ratio=0.3, feature_mask=False, feature_mask_ratio=0.1, time_shift=False,
+                 time_shift_ratio=0.1, channel_drop=False, channel_drop_prob=0.1),
+            dict(spec_augment=False, time_mask_ratio=0.2, feature_mask=False, feature_mask_ratio=0.1, time_shift=True,
+                 time_shift_ratio=0.25, channel_drop=True, channel_drop_prob=0.5)]
+    g = torch.Generator().manual_seed(3)
+    for ci, cfg in enumerate(cfgs):
+        for seed, (B, T, F) in enumerate([(3, 321, 180), (2, 37, 65), (1, 5, 9)]):
+            stored = torch.randn(B, F, T, generator=g) if layout == "bft_view" else torch.randn(B, T, F, generator=g)
+            x = stored.to("cuda", dtype=dtype)
+            x = x.transpose(1, 2) if layout == "bft_view" else x
+            random.seed(100 * ci + seed); torch.manual_seed(100 * ci + seed)
+            want = _reference_pipeline(x, cfg)
+            random.seed(100 * ci + seed); torch.manual_seed(100 * ci + seed)
+            got = FusedAugment(gaussian_jitter=False, **cfg)(x)
+            assert got.shape == x.shape and got.dtype == x.dtype
+            assert torch.equal(got, want), (ci, B, T, F)
+            assert got.data_ptr() != x.data_ptr()
+
+
+def test_fused_augment_jitter_statistics_and_errors():
+    from dfa_amd.augmentation import FusedAugment
+    x = torch.zeros(8, 321, 180, device="cuda")
+    aug = FusedAugment(gaussian_jitter=True, gaussian_jitter_std=0.05, seed=11)
+    a, b = aug(x), aug(x)
+    assert not torch.equal(a, b)                                   # a new noise field per call
+    for n in (a, b):
+        assert abs(float(n.mean())) < 5e-4 and abs(float(n.std()) - 0.05) < 5e-4
+        k = float(((n / 0.05) ** 4).mean())                        # Gaussian kurtosis 3
+        assert abs(k - 3.0) < 0.1
+    again = FusedAugment(gaussian_jitter=True, gaussian_jitter_std=0.05, seed=11)(x)
+    assert torch.equal(a, again)                                   # a pure function of (seed, call index)
+    out16 = FusedAugment(gaussian_jitter=True, gaussian_jitter_std=0.05, seed=11, out_dtype=torch.bfloat16)(x)
+    assert out16.dtype == torch.bfloat16 and torch.equal(out16, a.to(torch.bfloat16))
+    with pytest.raises(RuntimeError):
+        aug(torch.zeros(2, 8, 8))
