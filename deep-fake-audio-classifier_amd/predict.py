@@ -47,6 +47,28 @@ def predict_scores(model, features: torch.Tensor, batch_size: int = 32, device="
     return torch.cat(outs) if outs else torch.empty(0, device=device)
 
 
+@torch.no_grad()
+def extract_embeddings(model, features: torch.Tensor, batch_size: int = 256, device="cuda", swap_tf: bool = True,
+                       rank: int = 0, world: int = 1, input_dtype=None):
+    """Bulk export of the block-3 time-mean embedding [N, 128*F] (what src/embedding_anomaly.py:49-73 collects with
+    forward hooks for its OC-SVM / GMM stage) together with the logits [N]: the HIP forward writes the embedding rows
+    straight from the block-3 epilogue (`return_embedding=True`), so the export costs one extra 92 KB store per utterance.
+    Returns (embeddings, logits) as host tensors (this rank's shard when world > 1)."""
+    from .dataloaders import FlatBatcher
+    if not hasattr(model, "_eval_forward"):
+        raise ValueError("extract_embeddings needs the CNN2D model (the 1D CNN has no [128*F] embedding)")
+    model.eval()
+    embs, logits = [], []
+    for feats, _ in FlatBatcher(features, None, batch_size, device=device, rank=rank, world=world, dtype=input_dtype):
+        x = feats.transpose(1, 2) if swap_tf else feats
+        lg, e = model(x, return_embedding=True)
+        embs.append(e.cpu())
+        logits.append(lg.squeeze(-1).cpu())
+    if not embs:
+        return torch.empty(0, 0), torch.empty(0)
+    return torch.cat(embs), torch.cat(logits)
+
+
 def write_predictions(uttids, scores, out_path: str) -> pd.DataFrame:
     """prediction.pkl exactly as src/predict.py:116-122 writes it (uttid object column, float64 predictions)."""
     scores = [float(s) for s in scores]

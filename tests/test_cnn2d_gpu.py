@@ -168,6 +168,24 @@ def test_cnn2d_block3_16x16x32_kernel_matches_32x32x16_kernel(golden):
         ctx.set_option("block3_m16", 1)
 
 
+def test_extract_embeddings_matches_per_batch_forward_and_oracle(golden):
+    """predict.extract_embeddings: the [N, 128*F] block-3 embedding export equals the per-call `return_embedding`
+    output, for any batch size, and the oracle's mean-over-T feature map (src/model.py:37-38)."""
+    from dfa_amd.predict import extract_embeddings, predict_scores
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd)
+    gen = torch.Generator().manual_seed(21)
+    stored = torch.randn(7, 180, 64, generator=gen)
+    emb, logits = extract_embeddings(model, stored, batch_size=3)
+    assert tuple(emb.shape) == (7, 128 * 180) and tuple(logits.shape) == (7,)
+    lg, e = model(stored.to("cuda").transpose(1, 2), return_embedding=True)
+    assert torch.equal(emb, e.cpu()) and torch.equal(logits, lg.squeeze(-1).cpu())
+    assert torch.equal(logits, predict_scores(model, stored, batch_size=4, apply_sigmoid=False).cpu())
+    _, inter = O.cnn2d_forward({k: np.asarray(v) for k, v in sd.items()}, stored.numpy().swapaxes(1, 2),
+                               return_intermediates=True)
+    np.testing.assert_allclose(emb.numpy(), inter["embedding"], atol=2e-5, rtol=1e-4)
+
+
 def test_cnn2d_batch_independence_full_size(golden):
     """BASELINE configs[1] shape [256,321,180]: every utterance's logit must equal the logit it gets in a batch of
     its own (eval mode has no cross-sample op) -- a size-independent property checked at the full benchmark size."""
