@@ -249,6 +249,16 @@ def test_predict_end_to_end_eer_parity(tmp_path, golden):
         want = O.calculate_eer(ref_scores.tolist(), labels.tolist())
         assert res["eer"] == want[0], (res, want)
         assert 0.0 < res["eer"] < 1.0          # non-degenerate: the metric is sensitive to rank changes
+    # the bf16 storage mode (the headline configuration): scores within the bf16-mode tolerance of the reference's, and
+    # the EER moves by at most one rank swap of the 96 utterances
+    out16 = str(tmp_path / "prediction_bf16.pkl")
+    predict.main(["--features", fp, "--checkpoint", ck, "--model", "cnn2d", "--out", out16, "--batch-size", "32",
+                  "--no-apply-sigmoid", "--precision", "bf16"])
+    got16 = pd.read_pickle(out16)
+    np.testing.assert_allclose(got16["predictions"].values, ref_logits.numpy(), atol=0.1, rtol=0)
+    eer16 = evaluation.score_prediction_file(out16, lp)["eer"]
+    eer32 = O.calculate_eer(ref_logits.tolist(), labels.tolist())[0]
+    assert abs(eer16 - eer32) <= 1.0 / min(int(labels.sum()), n - int(labels.sum())) + 1e-12, (eer16, eer32)
 
 
 def test_cnn2d_lds_dma_staging_matches_register_staging(golden):
