@@ -84,7 +84,7 @@ def timed_steps(torch, dist, model, x, steps, warmup, world):
     # is bracketed
     ctx.timing_reset()
     ctx.timing(True)
-    for _ in range(10):
+    for _ in range(30):
         model(x)
     ctx.timing(False)
     torch.cuda.synchronize()
