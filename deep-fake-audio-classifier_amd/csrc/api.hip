@@ -279,7 +279,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   if (fused12) {
     ScopedSlot ts(ctx, 1);
     DFA_HIP_CHECK(ctx, launch_conv12_fused(x, x_dtype, stride_b, stride_t, stride_f, m.c1pack, m.c1bias, m.c2.wpack, m.c2.bias, a2,
-                                           B, T, F, s));
+                                           B, T, F, s, ctx->lds_pipe));
   } else {
     ScopedSlot ts(ctx, 0);
     DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.w1, m.b1, a1, prec, B, T, F, s));
@@ -298,7 +298,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
     if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
       a.wpack = m.c3_m16;
-      DFA_HIP_CHECK(ctx, launch_cnn2d_block3_m16(a, s));
+      DFA_HIP_CHECK(ctx, launch_cnn2d_block3_m16(a, s, ctx->lds_pipe));
     } else {
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
     }

@@ -55,7 +55,8 @@ constexpr int NXLD = (NX + 255) / 256;
 static __device__ long long g_diag12[2048 * 4 * 8];
 #endif
 
-template <typename TX>
+// PIPE = false is the compiler-scheduled twin (plain LDS loads, same arithmetic): the GPU tests require bit-identical output
+template <typename TX, bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   using namespace c12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,11 +151,16 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   struct C1State { u32x2_t w0, w1; f32x16_t e, o; float v[16]; };
   auto c1_issue = [&](C1State& st, int j) {       // two window reads (asm: they join the counted LDS pipeline)
     const unsigned addr = c1_win + (j & 1) * XW_BYTES;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(st.w0) : "v"(addr));
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(st.w1) : "v"(addr), "n"(XW_ROWB));
+    if constexpr (PIPE) {
+      asm volatile("ds_read_b64 %0, %1" : "=v"(st.w0) : "v"(addr));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(st.w1) : "v"(addr), "n"(XW_ROWB));
+    } else {
+      st.w0 = *(const u32x2_t*)((const __attribute__((address_space(3))) char*)(size_t)addr);
+      st.w1 = *(const u32x2_t*)((const __attribute__((address_space(3))) char*)(size_t)(addr + XW_ROWB));
+    }
   };
   auto c1_mfma = [&](C1State& st) {               // the windows have landed (caller's counted wait)
-    asm volatile("" : "+v"(st.w0), "+v"(st.w1));
+    if constexpr (PIPE) asm volatile("" : "+v"(st.w0), "+v"(st.w1));
     const uint4 xv = make_uint4(st.w0[0], st.w0[1], st.w1[0], st.w1[1]);
     st.e = Mma<bf16_t>::run(c1w[0], xv, bias1);
     st.o = Mma<bf16_t>::run(c1w[2], xv, bias1);
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   auto produce_now = [&](int j, int ringblk) {
     C1State st;
     c1_issue(st, j);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st.w0), "+v"(st.w1));
+    if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st.w0), "+v"(st.w1));
     c1_mfma(st);
     c1_relu(st, j);
     c1_store(st, ringblk);
@@ -229,14 +235,14 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
       if constexpr (s < NR) {
         constexpr int i = s / (3 * NKG), dx = (s / NKG) % 3, kg = s % NKG;
         constexpr int ringrow = (BR * PH + 2 * RPI + i) % (3 * BR);
-        xbuf[s % PF] = lds_frag<ringrow * ROWB, true>(lds0 + (xa[dx] ^ (kg << 5)));
+        xbuf[s % PF] = lds_frag<ringrow * ROWB, PIPE>(lds0 + (xa[dx] ^ (kg << 5)));
         if constexpr (s == 1) c1_issue(c1, it + 2);
       }
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
         constexpr int i = c / (3 * NKG), dx = (c / NKG) % 3, kg = c % NKG;
         constexpr int young = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
-        lds_wait<young>(xbuf[c % PF]);
+        if constexpr (PIPE) lds_wait<young>(xbuf[c % PF]);
         const uint4 xv = __builtin_bit_cast(uint4, xbuf[c % PF]);
         if constexpr (i <= 2) acc0 = Mma<bf16_t>::run(w[i * 3 + dx][kg], xv, acc0);
         if constexpr (i >= 1) acc1 = Mma<bf16_t>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
@@ -252,9 +258,9 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     };
     {
       const unsigned ba = lds0 + BIAS2_OFF + (nsl * 32 + 4 * h) * 4;
-      u32x4_t b0 = lds_frag<0, true>(ba), b1 = lds_frag<32, true>(ba), b2 = lds_frag<64, true>(ba), b3 = lds_frag<96, true>(ba);
+      u32x4_t b0 = lds_frag<0, PIPE>(ba), b1 = lds_frag<32, PIPE>(ba), b2 = lds_frag<64, PIPE>(ba), b3 = lds_frag<96, PIPE>(ba);
       static_for(std::make_integer_sequence<int, PF - 1>{}, step);
-      lds_wait4<PF - 1 + 2>(b0, b1, b2, b3);     // + the two window reads issued behind fragment read 1
+      if constexpr (PIPE) lds_wait4<PF - 1 + 2>(b0, b1, b2, b3);     // + the two window reads issued behind fragment read 1
       const u32x4_t bq[4] = {b0, b1, b2, b3};
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -335,26 +341,30 @@ hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pac
   return hipGetLastError();
 }
 
+template <typename TX, bool PIPE>
+static hipError_t launch_conv12_t(const Conv12Args& a, int B, hipStream_t s) {
+  auto kern = conv12_fused_kernel<TX, PIPE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, c12::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack,
                                const float* c1bias, const uint4* wpack2, const float* bias2, void* a2, int B, int T,
-                               int F, hipStream_t s) {
+                               int F, hipStream_t s, int pipe) {
   Conv12Args a{};
   a.x = x; a.sxb = sb; a.sxt = st; a.sxf = sf;
   a.c1pack = c1pack; a.c1bias = c1bias; a.wpack = wpack2; a.bias = bias2; a.out = (bf16_t*)a2;
   a.B = B; a.T = T; a.F = F; a.H1 = T / 2; a.nstrips = (F + c12::SW - 1) / c12::SW;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv12_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       c12::LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv12_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, c12::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (x_dtype == DFA_DTYPE_BF16)
-    hipLaunchKernelGGL(conv12_fused_kernel<bf16_t>, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
-  else
-    hipLaunchKernelGGL(conv12_fused_kernel<float>, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
+  hipError_t le;
+  if (x_dtype == DFA_DTYPE_BF16) le = pipe ? launch_conv12_t<bf16_t, true>(a, B, s) : launch_conv12_t<bf16_t, false>(a, B, s);
+  else le = pipe ? launch_conv12_t<float, true>(a, B, s) : launch_conv12_t<float, false>(a, B, s);
+  if (le != hipSuccess) return le;
 #ifdef DFA_STAMPS
   {
     static int calls = 0;

@@ -31,6 +31,8 @@ __device__ __forceinline__ f32x4_t mma16(const uint4& w, const uint4& x, f32x4_t
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
 }
 
+// PIPE = false: the compiler-scheduled twin (same arithmetic; the GPU tests require bit-identical output)
+template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   using namespace m16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,13 +126,13 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
       if constexpr (s < NR) {
         constexpr int i = s / 12, dx = (s / 4) % 3, kk = (s / 2) % 2, pb = s % 2;
         constexpr int ringrow = (BR * PH + i) % (3 * BR);
-        xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, true>(lds0 + (xa[dx] ^ (kk << 6)));
+        xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, PIPE>(lds0 + (xa[dx] ^ (kk << 6)));
       }
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
         constexpr int i = c / 12, dx = (c / 4) % 3, kk = (c / 2) % 2, pb = c % 2;
         constexpr int young = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
-        lds_wait<young>(xbuf[c % PF]);
+        if constexpr (PIPE) lds_wait<young>(xbuf[c % PF]);
         const uint4 xv = __builtin_bit_cast(uint4, xbuf[c % PF]);
 #pragma unroll
         for (int ca = 0; ca < 2; ++ca) {
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     };
     {   // bias = accumulator init: channels 16*ca + 4*q + e of this wave's slice
       const unsigned ba = lds0 + RING_BYTES + (nsl * 32 + 4 * q) * 4;
-      u32x4_t b0 = lds_frag<0, true>(ba), b1 = lds_frag<64, true>(ba);
+      u32x4_t b0 = lds_frag<0, PIPE>(ba), b1 = lds_frag<64, PIPE>(ba);
       static_for(std::make_integer_sequence<int, PF - 1>{}, step);
-      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(PF - 1));
+      if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(PF - 1));
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb) {
         acc0[0][pb] = acc1[0][pb] = __builtin_bit_cast(f32x4_t, b0);
@@ -240,18 +242,23 @@ hipError_t launch_fold_pack_conv3x3_m16(const float* w, const float* b, const fl
   return hipGetLastError();
 }
 
-hipError_t launch_cnn2d_block3_m16(const ConvArgs& a0, hipStream_t stream) {
-  ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+template <bool PIPE>
+static hipError_t launch_m16_t(const ConvArgs& a, hipStream_t stream) {
+  auto kern = conv3_m16_meant_kernel<PIPE>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3_m16_meant_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       m16::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m16::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3_m16_meant_kernel, dim3(a.B * a.nstrips, a.COUT / 128, 1), dim3(256), m16::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, a.COUT / 128, 1), dim3(256), m16::LDS_BYTES, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_cnn2d_block3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
+  ConvArgs a = a0;
+  a.nstrips = (a.W + 31) / 32;
+  return pipe ? launch_m16_t<true>(a, stream) : launch_m16_t<false>(a, stream);
 }
 
 }  // namespace dfa

@@ -284,6 +284,32 @@ def test_cnn2d_lds_dma_staging_matches_register_staging(golden):
         ctx.set_option("block3_m16", 1)
 
 
+def test_cnn2d_product_kernels_match_their_compiler_scheduled_twins(golden):
+    """The two kernels of the headline path -- conv12_fused_kernel and conv3_m16_meant_kernel -- read their LDS operands
+    through the asm pipeline; with lds_pipe = 0 the same kernels run with compiler-scheduled LDS loads.  Same MFMAs in
+    the same order: logits and embeddings must be bit-identical, for bf16 and fp32 features, ragged widths included."""
+    from dfa_amd import _lib
+    from dfa_amd.model import CNN2D
+    sd, g = golden("cnn2d_eval")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(13)
+    cases = [torch.from_numpy(g["t321.x_stored"]).to("cuda").to(torch.bfloat16).transpose(1, 2),
+             torch.from_numpy(g["t7.x_stored"]).to("cuda").transpose(1, 2),
+             (torch.randn(200, 180, 321, generator=gen) * 3.0).to("cuda", dtype=torch.bfloat16).transpose(1, 2),
+             torch.randn(3, 65, 40, generator=gen).to("cuda", dtype=torch.bfloat16).transpose(1, 2)]
+    try:
+        for x in cases:
+            F = x.shape[2]
+            model = _model_from_sd(sd, precision="bf16") if F == 180 else CNN2D(in_features=F, precision="bf16").to("cuda").eval()
+            ctx.set_option("lds_pipe", 0)
+            l0, e0 = model(x, return_embedding=True)
+            ctx.set_option("lds_pipe", 1)
+            l1, e1 = model(x, return_embedding=True)
+            assert torch.equal(l0, l1) and torch.equal(e0, e1), tuple(x.shape)
+    finally:
+        ctx.set_option("lds_pipe", 1)
+
+
 def test_cnn2d_pipelined_lds_reads_match_compiler_scheduled_twins(golden):
     """The asm-pipelined fragment reads (conv3x3_mfma.h, PFD > 0) change the instruction schedule only: every pipelined
     bf16 kernel must be bit-identical to its compiler-scheduled twin (lds_pipe = 0), for both staging paths, at small
