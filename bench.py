@@ -171,6 +171,37 @@ def train_step_metric(torch, device, B, steps=20, warmup=5):
             "what": "fwd + bwd + fused AdamW, dropout 0.2, label smoothing 0.05 (src/train.py:71-76), 1 GPU"}
 
 
+def other_models_metric(torch, device, B, steps=20, warmup=5):
+    """Secondary paths of SURVEY section 8 at the same batch (rank 0, N = 1 only): CNN1D forward (a3), the auto-encoder's
+    anomaly score with the z-score and per-sample MSE fused in (a4/a5/a13), and the auto-encoder training step."""
+    from dfa_amd.model_cae import ConvAutoencoder
+    from dfa_amd.model_cnn1d import CNN1D
+    g = torch.Generator().manual_seed(77)
+    stored = (torch.randn(B, F, T, generator=g) * 3.2 - 0.07).to(device)
+    x = stored.transpose(1, 2)
+
+    def rate(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3)}
+
+    torch.manual_seed(0)
+    out = {}
+    m1 = CNN1D(in_features=F).to(device).eval()
+    out["cnn1d_fwd_fp32"] = rate(lambda: m1(x))
+    mean, std = torch.zeros(F, device=device), torch.ones(F, device=device)
+    cae = ConvAutoencoder(precision="bf16").to(device).eval()
+    x16 = x.to(torch.bfloat16)
+    out["cae_score_bf16"] = rate(lambda: cae.score(x16, mean, std))
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -248,6 +279,7 @@ def main():
         }
         if world == 1:
             line["train_step"] = train_step_metric(torch, device, B)
+            line["other_models"] = other_models_metric(torch, device, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_seconds)
         print(json.dumps(line), flush=True)
