@@ -28,7 +28,7 @@ const int kDCin[3] = {256, 128, 64};
 struct CaeTrainPlan {
   int H[5], W[5], Hd[4], Wd[4];
   bool ok;
-  size_t e[4], z[4], zd[3], d[3], dd[3], dzd[3], de[4], dz[4], zp, xf, raw, stats, sums, wq, dwq, rec, partial, total;
+  size_t e[4], z[4], zd[3], d[3], dd[3], dzd[3], de[4], dz[4], zp, xf, raw, stats, sums, wq, dwq, rec, partial, partial_bytes, total;
 };
 
 CaeTrainPlan plan_cae_train(int B, int T, int F, int prec) {
@@ -76,6 +76,7 @@ CaeTrainPlan plan_cae_train(int B, int T, int F, int prec) {
   pb = std::max(pb, (size_t)cl_stats_blocks((size_t)B * T * F, &ppb) * 256 * 2 * 4);
   pb = std::max(pb, (size_t)cae_dec4_bwd_blocks() * 132 * 4);
   p.partial = take(pb);
+  p.partial_bytes = pb;
   p.total = off;
   return p;
 }
@@ -263,9 +264,14 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     DFA_HIP_CHECK(ctx, launch_cast_from_f32(prec, xf, dx, (size_t)P * Cin, s));
     // weight gradient: dWq[Cin x 4Cout] = X^T . Zp   (K = P, split over workgroups)
     const void* xin = (l == 0) ? ws + pl.e[3] : ws + pl.d[l - 1];
-    DFA_HIP_CHECK(ctx, launch_gemm_f32(bf, xin, 1, Cin, bf, ws + pl.zp, 4 * Cout, 1, partial, Cin, 4 * Cout, (int)P, kGemmSplit, s));
     float* dwq = (float*)(ws + pl.dwq);
-    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, kGemmSplit, Cin * 4 * Cout, 1.0f, dwq, s, nullptr));
+    int nparts = kGemmSplit;
+    if (bf) {   // bf16 mode: transposed-read bf16 MFMA GEMM (gemm_tn_bf16.hip)
+      DFA_HIP_CHECK(ctx, launch_gemm_tn_bf16(xin, ws + pl.zp, partial, pl.partial_bytes / sizeof(float), Cin, 4 * Cout, (int)P, &nparts, s));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_gemm_f32(bf, xin, 1, Cin, bf, ws + pl.zp, 4 * Cout, 1, partial, Cin, 4 * Cout, (int)P, kGemmSplit, s));
+    }
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nparts, Cin * 4 * Cout, 1.0f, dwq, s, nullptr));
     DFA_HIP_CHECK(ctx, launch_convt_q_to_w(dwq, grads[16 + 4 * l], Cin, Cout, s));
   }
   // ---- encoder blocks 4, 3, 2

@@ -156,6 +156,8 @@ hipError_t launch_fold_pack_convt2x2(const float* w, const float* b, const float
                                      const float* mean, const float* var, int cin, int cout, int prec, uint4* wpack,
                                      float* bias, hipStream_t s, int fold = 1);
 // gemm_f32.hip
+hipError_t launch_gemm_tn_bf16(const void* X, const void* Z, float* partial, size_t partial_floats, int M, int N, int K,
+                               int* nparts, hipStream_t s);
 hipError_t launch_gemm_f32(int a_bf16, const void* A, int64_t sam, int64_t sak, int b_bf16, const void* Bm, int64_t sbk,
                            int64_t sbn, float* C, int M, int N, int K, int ksplit, hipStream_t s);
 // conv1.hip
