@@ -171,7 +171,7 @@ __global__ void conv1d_dgrad_pack_kernel(const float* __restrict__ w, float* __r
 }
 
 // ================================================================================================ launchers
-constexpr int kCmChunks = 16;
+constexpr int kCmChunks = 64;   // batch chunks of the channel-major reductions: 16 left the 32->64 weight gradient at 128 blocks on 256 CUs
 int cm_chunks(int B) { return B < kCmChunks ? B : kCmChunks; }
 
 hipError_t launch_cm_stats(const float* z, float* partial, int B, int C, int T, hipStream_t s) {
