@@ -174,6 +174,7 @@ hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, con
                          float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu = true);
 // train_cnn1d.hip
 int cm_chunks(int B);
+int conv1d_wgrad_chunks(int B);
 hipError_t launch_cm_stats(const float* z, float* partial, int B, int C, int T, hipStream_t s);
 hipError_t launch_cm_bn_relu_drop(const float* z, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, float* h, int B, int C, int T, const DropCfg& dc, hipStream_t s);

@@ -295,8 +295,9 @@ Train1dPlan plan_train1d(int B, int T, int F) {
   p.sums = take((32 + 64 + 128) * 2 * 4);
   const size_t nch = (size_t)cm_chunks(B);
   size_t pb = nch * 128 * 2 * 4;
-  pb = std::max(pb, nch * ((size_t)32 * F * 3 + 32) * 4);
-  pb = std::max(pb, nch * ((size_t)128 * 64 * 3 + 128) * 4);
+  const size_t wch = (size_t)conv1d_wgrad_chunks(B);
+  pb = std::max(pb, wch * ((size_t)32 * F * 3 + 32) * 4);
+  pb = std::max(pb, wch * ((size_t)128 * 64 * 3 + 128) * 4);
   p.partial = take(pb);
   p.total = off;
   return p;

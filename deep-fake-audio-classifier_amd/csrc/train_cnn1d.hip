@@ -160,6 +160,76 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const float* __restri
   if (blockIdx.y == 0 && cl == 0) rec[(size_t)Cout * Cin * 3 + o] = ab;
 }
 
+// ---- the same weight gradient on the fp32 matrix cores: three GEMMs [32 o x t] . [t x 32 c] (one per tap) sharing the dz
+// operand; both operands are channel-major with t contiguous, i.e. K-contiguous rows, so v_mfma_f32_32x32x2_f32 takes
+// them straight from LDS tiles (lane = channel, k = frame parity).  One wave per (o tile, c tile, utterance chunk):
+// 96 MFMAs per 64-frame slab; the VALU kernel above spent 4 LDS reads on every 3 FMAs and ran at 128-512 blocks.
+__global__ __launch_bounds__(64) void conv1d_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ h,
+                                                               int64_t hsb, int64_t hsc, int64_t hst,
+                                                               float* __restrict__ partial, int B, int Cin, int Cout, int T,
+                                                               int bchunk) {
+  __shared__ float dzs[32][W1D_TT + 1];
+  __shared__ float hs[32][W1D_TT + 3];
+  const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+  const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32, ch = blockIdx.z;
+  const int b0 = ch * bchunk, b1 = min(B, b0 + bchunk);
+  f32x16_t acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  float ab = 0.f;
+  // slab = (utterance, 64 frames); the next slab's 66 values per lane are fetched into registers while the MFMAs of the
+  // current one run (all loads of a slab are issued back to back: one latency per slab, not one per row)
+  const int nslab_t = (T + W1D_TT - 1) / W1D_TT;
+  const int nslab = (b1 - b0) * nslab_t;
+  float rdz[32], rh[32], rh2 = 0.f;
+  auto fetch = [&](int sl) {
+    const int b = b0 + sl / nslab_t, t0 = (sl % nslab_t) * W1D_TT;
+#pragma unroll
+    for (int oo = 0; oo < 32; ++oo)
+      rdz[oo] = (t0 + lane < T) ? dz[((size_t)b * Cout + o0 + oo) * T + t0 + lane] : 0.f;
+    const int t = t0 - 1 + lane;
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) {
+      const int ci = c0 + cc;
+      rh[cc] = (ci < Cin && t >= 0 && t < T) ? h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)t * hst] : 0.f;
+    }
+    // the two extra frames of the 66-frame window: lane = (channel, which frame)
+    const int ci2 = c0 + (lane & 31), t2 = t0 + 63 + (lane >> 5);
+    rh2 = (ci2 < Cin && t2 < T) ? h[(int64_t)b * hsb + (int64_t)ci2 * hsc + (int64_t)t2 * hst] : 0.f;
+  };
+  if (nslab > 0) fetch(0);
+  for (int sl = 0; sl < nslab; ++sl) {
+    __syncthreads();
+#pragma unroll
+    for (int oo = 0; oo < 32; ++oo) dzs[oo][lane] = rdz[oo];
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) hs[cc][lane] = rh[cc];
+    hs[lane & 31][64 + (lane >> 5)] = rh2;
+    __syncthreads();
+    if (sl + 1 < nslab) fetch(sl + 1);
+#pragma unroll 8
+    for (int tt = 0; tt < W1D_TT; tt += 2) {
+      const float a = dzs[r][tt + hh];
+      ab += a;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hs[r][tt + hh + k], acc[k], 0, 0, 0);
+    }
+  }
+  float* rec = partial + (size_t)ch * ((size_t)Cout * Cin * 3 + Cout);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = o0 + (i & 3) + 8 * (i >> 2) + 4 * hh, c = c0 + r;
+      if (c < Cin) rec[((size_t)o * Cin + c) * 3 + k] = acc[k][i];
+    }
+  ab += __shfl_xor(ab, 32, 64);
+  if (blockIdx.y == 0 && hh == 0) rec[(size_t)Cout * Cin * 3 + o0 + r] = ab;
+}
+
 // data-gradient weights of Conv1d: W'[c][o][k'] = W[o][c][2-k']  (a Conv1d with Cin' = Cout, Cout' = Cin)
 __global__ void conv1d_dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, float* __restrict__ zero_bias,
                                          int cin, int cout) {
@@ -168,6 +238,27 @@ __global__ void conv1d_dgrad_pack_kernel(const float* __restrict__ w, float* __r
   if (i >= cin * cout * 3) return;
   const int k = i % 3, o = (i / 3) % cout, c = i / (3 * cout);
   wt[i] = w[((size_t)o * cin + c) * 3 + (2 - k)];
+}
+
+// whole partial record in one launch: elements [0, n0) -> out0, [n0, n0 + n1) -> out1; 64 elements x 4 record groups per
+// block, fp64 sums combined in a fixed order (as reduce_wgrad_record_kernel of train_elem.hip)
+__global__ __launch_bounds__(256) void reduce_record2_kernel(const float* __restrict__ partial, int nparts, int stride, int n0,
+                                                             float* __restrict__ out0, int n1, float* __restrict__ out1) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane, total = n0 + n1;
+  double s = 0.0;
+  if (e < total) {
+    const int k0 = (int)((long)pg * nparts / 4), k1 = (int)((long)(pg + 1) * nparts / 4);
+    const float* p = partial + (size_t)k0 * stride + e;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k, p += stride) s += (double)*p;
+  }
+  red[pg][lane] = s;
+  __syncthreads();
+  if (pg != 0 || e >= total) return;
+  const float v = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (e < n0) out0[e] = v; else out1[e - n0] = v;
 }
 
 // ================================================================================================ launchers
@@ -211,17 +302,20 @@ hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const fl
     hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums, up, dz, C, T, n, inv_n, dc);
   return hipGetLastError();
 }
-// partial: cm_chunks(B) * (Cout*Cin*3 + Cout) floats
+// partial: conv1d_wgrad_chunks(B) * (Cout*Cin*3 + Cout) floats
+int conv1d_wgrad_chunks(int B) { return B < 256 ? B : 256; }
 hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
                                float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s) {
-  const int nch = cm_chunks(B), bchunk = (B + nch - 1) / nch;
-  hipLaunchKernelGGL(conv1d_wgrad_kernel, dim3(Cout / 16, (Cin + 15) / 16, nch), dim3(256), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk);
+  const int nch = conv1d_wgrad_chunks(B), bchunk = (B + nch - 1) / nch;
+  if (Cout % 32 == 0)
+    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, dim3(Cout / 32, (Cin + 31) / 32, nch), dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk);
+  else
+    hipLaunchKernelGGL(conv1d_wgrad_kernel, dim3(Cout / 16, (Cin + 15) / 16, nch), dim3(256), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int n = Cout * Cin * 3;
-  e = launch_reduce_partials_strided(partial, nch, n + Cout, 0, n, dw, s);
-  if (e != hipSuccess) return e;
-  return launch_reduce_partials_strided(partial, nch, n + Cout, n, Cout, db, s);
+  hipLaunchKernelGGL(reduce_record2_kernel, dim3((n + Cout + 63) / 64), dim3(256), 0, s, partial, nch, n + Cout, n, dw, Cout, db);
+  return hipGetLastError();
 }
 hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias, int cin, int cout, hipStream_t s) {
   const int n = cin * cout * 3;
