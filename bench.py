@@ -82,9 +82,12 @@ def timed_steps(torch, dist, model, x, steps, warmup, world):
     # per-kernel breakdown from an untimed pass (every launch bracketed by events) BEFORE the warm-up steps, so that the
     # warm-up runs right up to the barrier of the timed region; inside the timed region only the dominant kernel (slot 2)
     # is bracketed
+    for _ in range(10):                     # clock ramp / first-touch launches stay out of the per-kernel averages
+        model(x)
+    torch.cuda.synchronize()
     ctx.timing_reset()
     ctx.timing(True)
-    for _ in range(30):
+    for _ in range(20):
         model(x)
     ctx.timing(False)
     torch.cuda.synchronize()
