@@ -276,25 +276,35 @@ __global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict_
 // ---- backward of Linear(K,1): demb[b][j] = dlogit[b]*w[j];  dw[j] = sum_b dlogit[b]*emb[b][j];  db = sum_b dlogit[b]
 // tc > 0: demb is written TRANSPOSED per utterance, j = c*tw + f  ->  demb[b][f][c] (tc channels, tw columns), the
 // channels-last order the BatchNorm backward of block 3 reads 8 channels at a time.
-__global__ void linear_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
-                                  const float* __restrict__ emb, float* __restrict__ demb, float* __restrict__ dw,
-                                  float* __restrict__ db, int B, int K, int tc, int tw) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) {
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ w,
+                                                         const float* __restrict__ emb, float* __restrict__ demb,
+                                                         float* __restrict__ dw, float* __restrict__ db, int B, int K, int tc,
+                                                         int tw) {
+  // block = 32 columns j x 8 utterance groups: a thread walks B/8 utterances (one thread per column walked all B with a
+  // dependent load->fma chain: 86 us at B = 256); the 8 partial dw sums meet in LDS in a fixed order
+  __shared__ float red[8][32];
+  const int jl = threadIdx.x & 31, bg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += dlogits[b];
     db[0] = s;
   }
-  if (j >= K) return;
-  const float wj = w[j];
-  const int jt = (tc > 0) ? (j % tw) * tc + j / tw : j;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float d = dlogits[b];
-    demb[(size_t)b * K + jt] = d * wj;
-    s = fmaf(d, emb[(size_t)b * K + j], s);
+  if (j < K) {
+    const float wj = w[j];
+    const int jt = (tc > 0) ? (j % tw) * tc + j / tw : j;
+#pragma unroll 4
+    for (int b = bg; b < B; b += 8) {
+      const float d = dlogits[b];
+      demb[(size_t)b * K + jt] = d * wj;
+      s = fmaf(d, emb[(size_t)b * K + j], s);
+    }
   }
-  dw[j] = s;
+  red[bg][jl] = s;
+  __syncthreads();
+  if (bg == 0 && j < K)
+    dw[j] = ((red[0][jl] + red[1][jl]) + (red[2][jl] + red[3][jl])) + ((red[4][jl] + red[5][jl]) + (red[6][jl] + red[7][jl]));
 }
 
 // ---- BatchNorm backward.  Upstream gradient dy of the BN *output* y = gamma*xhat+beta after the ReLU mask:
@@ -571,7 +581,7 @@ hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, cons
 
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
                              int B, int K, hipStream_t s, int tc, int tw) {
-  hipLaunchKernelGGL(linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, s, dlogits, w, emb, demb, dw, db, B, K, tc, tw);
+  hipLaunchKernelGGL(linear_bwd_kernel, dim3((K + 31) / 32), dim3(256), 0, s, dlogits, w, emb, demb, dw, db, B, K, tc, tw);
   return hipGetLastError();
 }
 
