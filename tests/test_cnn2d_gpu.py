@@ -118,6 +118,11 @@ def test_cnn2d_fused_blocks_1_2_match_two_kernel_path_and_oracle(golden):
              ("F61T5", torch.randn(2, 5, 61, generator=gen), False), ("F30", torch.randn(1, 30, 322, generator=gen), True),
              ("b64", torch.randn(64, 180, 321, generator=gen) * 3, True)]
     try:
+        # non-dense strides: every other utterance and a frame window of a larger stored tensor
+        big = torch.randn(6, 180, 400, generator=gen).to("cuda").to(torch.bfloat16)
+        view = big[::2, :, 37:358].transpose(1, 2)
+        model = _model_from_sd(sd, precision="bf16")
+        assert torch.equal(model(view), model(view.contiguous()))
         for name, stored, is_bft in cases:
             xb = stored.to("cuda").to(torch.bfloat16)
             xb = xb.transpose(1, 2) if is_bft else xb        # [B,T,F] view of [B,F,T] storage, or contiguous [B,T,F]
