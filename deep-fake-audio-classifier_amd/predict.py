@@ -88,6 +88,7 @@ def parse_args(argv=None):
     p.add_argument("--batch-size", type=int, default=32)
     p.add_argument("--num-workers", type=int, default=2)
     p.add_argument("--device", default=None, help="cuda (the HIP path has no CPU fallback)")
+    _add_embedding_flag(p)
     p.add_argument("--in-features", type=int, default=180)
     p.add_argument("--dropout", type=float, default=0.3)
     p.add_argument("--apply-sigmoid", action="store_true", default=True)
@@ -98,6 +99,11 @@ def parse_args(argv=None):
     sw.add_argument("--no-swap-tf", dest="swap_tf", action="store_false")
     p.set_defaults(swap_tf=True)
     return p.parse_args(argv)
+
+
+def _add_embedding_flag(p):
+    p.add_argument("--embeddings-out", default=None,
+                   help="also write the block-3 embeddings [N, 128*F] (+ uttids, logits) to this .pt file (cnn2d only)")
 
 
 def main(argv=None):
@@ -114,6 +120,9 @@ def main(argv=None):
     scores = predict_scores(model, feats, batch_size=args.batch_size, device=device, apply_sigmoid=apply_sigmoid,
                             swap_tf=args.swap_tf)
     write_predictions(features_df["uttid"].values, scores.cpu().tolist(), args.out)
+    if args.embeddings_out:
+        emb, logits = extract_embeddings(model, feats, batch_size=max(args.batch_size, 256), device=device, swap_tf=args.swap_tf)
+        torch.save({"uttid": list(features_df["uttid"].values), "embeddings": emb, "logits": logits}, args.embeddings_out)
 
 
 if __name__ == "__main__":

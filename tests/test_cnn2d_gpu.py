@@ -261,6 +261,13 @@ def test_predict_end_to_end_eer_parity(tmp_path, golden):
                   "--no-apply-sigmoid", "--precision", "bf16"])
     got16 = pd.read_pickle(out16)
     np.testing.assert_allclose(got16["predictions"].values, ref_logits.numpy(), atol=0.1, rtol=0)
+    # --embeddings-out: the [N, 128*F] export next to the predictions, consistent with the scores it came with
+    eo = str(tmp_path / "emb.pt")
+    predict.main(["--features", fp, "--checkpoint", ck, "--model", "cnn2d", "--out", str(tmp_path / "p3.pkl"), "--batch-size",
+                  "32", "--no-apply-sigmoid", "--embeddings-out", eo])
+    blob = torch.load(eo)
+    assert list(blob["uttid"]) == list(fdf["uttid"]) and tuple(blob["embeddings"].shape) == (n, 128 * 180)
+    np.testing.assert_allclose(blob["logits"].numpy(), ref_logits.numpy(), atol=TOL_F32, rtol=0)
     eer16 = evaluation.score_prediction_file(out16, lp)["eer"]
     eer32 = O.calculate_eer(ref_logits.tolist(), labels.tolist())[0]
     assert abs(eer16 - eer32) <= 1.0 / min(int(labels.sum()), n - int(labels.sum())) + 1e-12, (eer16, eer32)
