@@ -145,9 +145,19 @@ def cpu_baseline(torch, sd_cpu, seconds):
         el = time.perf_counter() - t0
         if el >= seconds:
             break
-    return {"value": round(n / el, 2), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+    used = torch.get_num_threads()
+    # single-thread figure for normalisation (SURVEY section 8 d): one batch of 8 utterances
+    torch.set_num_threads(1)
+    R.cnn2d_forward(sd_cpu, xb[:1])
+    t1 = time.perf_counter()
+    R.cnn2d_forward(sd_cpu, xb[:8])
+    one = 8 / (time.perf_counter() - t1)
+    torch.set_num_threads(used)
+    return {"value": round(n / el, 2), "unit": "utterances/s", "cores": used, "kind": "port",
+            "single_thread_value": round(one, 2),
             "sample": f"{n} utterances ({n // 32} batches of 32, [32,321,180] fp32 strided view) in {el:.1f} s with "
-                      "oracle/torch_ref.py (plain PyTorch CPU ops restating src/model.py:33-42)"}
+                      "oracle/torch_ref.py (plain PyTorch CPU ops restating src/model.py:33-42); single-thread figure from "
+                      "one batch of 8"}
 
 
 def train_step_metric(torch, device, B, steps=20, warmup=5):
