@@ -21,7 +21,7 @@ namespace dfa {
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 namespace m16 {
-constexpr int PB = 128, CPP = 8, SP = 36, ROWB = SP * PB, BR = 2, NSL = 4, NT = 256, PF = 4;
+constexpr int PB = 128, CPP = 8, SP = 36, ROWB = SP * PB, BR = 2, NSL = 4, NT = 256;
 constexpr int NCH = BR * SP * CPP, NLD = (NCH + NT - 1) / NT;
 constexpr int RING_BYTES = 3 * BR * ROWB, BIAS_BYTES = NSL * 32 * 4, LDS_BYTES = RING_BYTES + BIAS_BYTES;
 __device__ __forceinline__ int swz(int slot) { return slot & 6; }
@@ -32,9 +32,13 @@ __device__ __forceinline__ f32x4_t mma16(const uint4& w, const uint4& x, f32x4_t
 }
 
 // PIPE = false: the compiler-scheduled twin (same arithmetic; the GPU tests require bit-identical output)
-template <bool PIPE>
+// TRAIN = true: the train-mode forward of the same layer (src/train.py:71): the pre-BatchNorm output z is stored (bf16)
+// and the per-channel sum / sum of squares of the stored values ride along for the batch statistics (per-workgroup
+// partials in conv3x3_mfma's STATS layout); the weights come unfolded, ReLU and the time mean are separate passes.
+template <bool PIPE, bool TRAIN = false>
 __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   using namespace m16;
+  constexpr int PF = TRAIN ? 2 : 4;      // fragment reads in flight (the train epilogue needs the registers)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     }
   };
 
-  f32x4_t cs[2][2];     // running column sums: [channel tile][pixel tile]
+  f32x4_t cs[2][2];     // eval: running column sums [channel tile][pixel tile]; TRAIN: [0][ca] = sum, [1][ca] = sum of squares
 #pragma unroll
   for (int ca = 0; ca < 2; ++ca)
 #pragma unroll
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
           if constexpr (i <= 2) acc0[ca][pb] = mma16(w[i * 3 + dx][kk][ca], xv, acc0[ca][pb]);
           if constexpr (i >= 1) acc1[ca][pb] = mma16(w[(i - 1) * 3 + dx][kk][ca], xv, acc1[ca][pb]);
         }
-        if constexpr (c == C_RELU0) {   // rows 0..2 done for acc0: its ReLU hides under acc1's last MFMAs
+        if constexpr (!TRAIN && c == C_RELU0) {   // rows 0..2 done for acc0: its ReLU hides under acc1's last MFMAs
 #pragma unroll
           for (int ca = 0; ca < 2; ++ca)
 #pragma unroll
@@ -163,6 +167,30 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     static_for(std::make_integer_sequence<int, NR>{}, [&](auto s_c) {
       step(std::integral_constant<int, decltype(s_c)::value + PF - 1>{});
     });
+    if constexpr (TRAIN) {
+      const bool r0 = t0 < H, r1 = t0 + 1 < H;                    // wave-uniform
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const int col = f0 + 16 * pb + p;
+        const bool cok = col < W;
+        bf16_t* z0 = (bf16_t*)a.out + (((size_t)b * H + t0) * W + col) * COUT + cout_base + nsl * 32 + 4 * q;
+        bf16_t* z1 = z0 + (size_t)W * COUT;
+#pragma unroll
+        for (int ca = 0; ca < 2; ++ca) {
+          // statistics of the fp32 accumulators (as the 32x32x16 kernel); rows / columns outside the image do not count
+          if (cok && r0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[0][ca][e] += acc0[ca][pb][e]; cs[1][ca][e] = fmaf(acc0[ca][pb][e], acc0[ca][pb][e], cs[1][ca][e]); }
+            *(uint2*)(z0 + 16 * ca) = make_uint2(pack_bf16x2(acc0[ca][pb][0], acc0[ca][pb][1]), pack_bf16x2(acc0[ca][pb][2], acc0[ca][pb][3]));
+          }
+          if (cok && r1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[0][ca][e] += acc1[ca][pb][e]; cs[1][ca][e] = fmaf(acc1[ca][pb][e], acc1[ca][pb][e], cs[1][ca][e]); }
+            *(uint2*)(z1 + 16 * ca) = make_uint2(pack_bf16x2(acc1[ca][pb][0], acc1[ca][pb][1]), pack_bf16x2(acc1[ca][pb][2], acc1[ca][pb][3]));
+          }
+        }
+      }
+    } else
     if (t0 + 1 < H) {   // wave-uniform
 #pragma unroll
       for (int ca = 0; ca < 2; ++ca)
@@ -193,6 +221,31 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
   }
 
+  if constexpr (TRAIN) {
+    // per-channel sums over this workgroup's pixels: the 16 pixel lanes of a quarter-wave hold the same 8 channels
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = cs[k][ca][e];
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          cs[k][ca][e] = v;
+        }
+    if (p == 0 && a.stats_partial) {
+      float* dst = a.stats_partial + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * (NSL * 32) + nsl * 32 + 4 * q) * 2;
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dst[(16 * ca + e) * 2] = cs[0][ca][e];
+          dst[(16 * ca + e) * 2 + 1] = cs[1][ca][e];
+        }
+    }
+    return;
+  }
   // embedding rows [b][channel][col]: 16 consecutive columns per (channel, quarter-wave)
 #pragma unroll
   for (int ca = 0; ca < 2; ++ca)
@@ -214,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 __global__ void fold_pack_conv3x3_m16_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                              const float* __restrict__ g, const float* __restrict__ beta,
                                              const float* __restrict__ mean, const float* __restrict__ var, int cin,
-                                             int cout, uint4* __restrict__ wpack) {
+                                             int cout, uint4* __restrict__ wpack, int fold) {
   const int total = (cout / 32) * 9 * 2 * 2 * 64;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   (void)b; (void)beta; (void)mean;
@@ -226,7 +279,7 @@ __global__ void fold_pack_conv3x3_m16_kernel(const float* __restrict__ w, const 
   const int tap = rest % 9;
   const int slice = rest / 9;
   const int co = slice * 32 + 16 * ca + (lane & 15), q = lane >> 4;
-  const float s = g[co] / sqrtf(var[co] + kBnEps);
+  const float s = fold ? g[co] / sqrtf(var[co] + kBnEps) : 1.f;   // fold = 0: raw weights (train mode)
   bf16_t v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = float_to_bf16(w[((size_t)co * cin + 32 * kk + 8 * q + j) * 9 + tap] * s);
@@ -235,16 +288,16 @@ __global__ void fold_pack_conv3x3_m16_kernel(const float* __restrict__ w, const 
 
 hipError_t launch_fold_pack_conv3x3_m16(const float* w, const float* b, const float* g, const float* beta,
                                         const float* mean, const float* var, int cin, int cout, uint4* wpack,
-                                        hipStream_t s) {
+                                        hipStream_t s, int fold) {
   const int total = (cout / 32) * 9 * 2 * 2 * 64;
   hipLaunchKernelGGL(fold_pack_conv3x3_m16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, b, g, beta, mean, var,
-                     cin, cout, wpack);
+                     cin, cout, wpack, fold);
   return hipGetLastError();
 }
 
-template <bool PIPE>
+template <bool PIPE, bool TRAIN>
 static hipError_t launch_m16_t(const ConvArgs& a, hipStream_t stream) {
-  auto kern = conv3_m16_meant_kernel<PIPE>;
+  auto kern = conv3_m16_meant_kernel<PIPE, TRAIN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, m16::LDS_BYTES);
@@ -258,7 +311,14 @@ static hipError_t launch_m16_t(const ConvArgs& a, hipStream_t stream) {
 hipError_t launch_cnn2d_block3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
   a.nstrips = (a.W + 31) / 32;
-  return pipe ? launch_m16_t<true>(a, stream) : launch_m16_t<false>(a, stream);
+  return pipe ? launch_m16_t<true, false>(a, stream) : launch_m16_t<false, false>(a, stream);
+}
+
+// train-mode forward of block 3: a.out = z [B][H][W][128] bf16, a.stats_partial = [B*nstrips][128][2]
+hipError_t launch_train_fwd3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
+  ConvArgs a = a0;
+  a.nstrips = (a.W + 31) / 32;
+  return pipe ? launch_m16_t<true, true>(a, stream) : launch_m16_t<false, true>(a, stream);
 }
 
 }  // namespace dfa

@@ -10,6 +10,7 @@ namespace dfa {
 // 0 selects their compiler-scheduled twins (bit-identical; GPU test), 1 the earlier one-wave-per-SIMD instantiations.
 static int g_train_conv_variant = 2;
 void set_train_conv_variant(int v) { g_train_conv_variant = v; }
+int train_conv_variant() { return g_train_conv_variant; }
 
 hipError_t launch_train_fwd2(int prec, const ConvArgs& a, hipStream_t s) {
   if (prec == DFA_PREC_BF16) {

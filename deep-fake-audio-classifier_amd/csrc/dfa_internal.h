@@ -246,11 +246,13 @@ hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const vo
                            float* db, int B, int H, int W, int nwg, hipStream_t s);
 // conv3x3_inst_*.hip
 hipError_t launch_fold_pack_conv3x3_m16(const float* w, const float* b, const float* g, const float* beta, const float* mean,
-                                        const float* var, int cin, int cout, uint4* wpack, hipStream_t s);
+                                        const float* var, int cin, int cout, uint4* wpack, hipStream_t s, int fold = 1);
+hipError_t launch_train_fwd3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_cnn2d_block3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
                                       int ci_off, int co_off, float* dw, float* db, hipStream_t s);
-void set_train_conv_variant(int v);   // conv3x3_inst_train.hip (process-wide test hook)
+void set_train_conv_variant(int v);
+int train_conv_variant();   // conv3x3_inst_train.hip (process-wide test hook)
 void set_wgrad_variant(int v);   // wgrad_mfma.hip: bf16 weight-gradient kernel selection (process-wide test hook)
 hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pack, float* c1bias, hipStream_t s);
 hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack, const float* c1bias,

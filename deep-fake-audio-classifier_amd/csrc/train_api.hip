@@ -132,6 +132,11 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   const int prec = precision;
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], nullptr, nullptr, nullptr, nullptr, 32, 0, 32, 64, prec, m.t2.wpack, m.t2.bias, s, 0));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 0, 64, 128, prec, m.t3.wpack, m.t3.bias, s, 0));
+  // bf16: the 16x16x32 image of the same raw weights, in the unused second half of the (fp32-sized) t3 buffer
+  uint4* t3_m16 = (uint4*)((char*)m.t3.wpack + (size_t)128 * 64 * 9 * 2);
+  const bool fwd3_m16 = prec == DFA_PREC_BF16 && train_conv_variant() != 1;   // 2: pipelined, 0: its compiler-scheduled twin
+  if (fwd3_m16)
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3_m16(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 128, t3_m16, s, 0));
   DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[6], 32, 64, 0, 64, prec, m.d2.wpack, m.d2.bias, s));
   {  // two Cin halves (see launch_train_dgrad3)
     const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
@@ -175,7 +180,12 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     ConvArgs a{};
     a.in = ws + pl.a2; a.wpack = m.t3.wpack; a.bias = m.t3.bias; a.out = ws + pl.z3;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.relu = 0; a.stats_partial = partial; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_train_fwd3(prec, a, s));
+    if (fwd3_m16) {
+      a.wpack = t3_m16;
+      DFA_HIP_CHECK(ctx, launch_train_fwd3_m16(a, s, train_conv_variant() == 2));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_train_fwd3(prec, a, s));
+    }
   }
   StatPtrs s3 = stat_ptrs(ws, pl, 2);
   DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * nstrips, 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, s));
