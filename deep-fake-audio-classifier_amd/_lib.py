@@ -122,6 +122,12 @@ class Context:
             raise RuntimeError(f"dfa_ctx_create(device={self.index}) failed: {self.lib.dfa_error_name(code).decode()}")
         self.handle = h
         self._ws = None
+        # A dfa_ctx has ONE weight slot per model class (cnn2d / cnn1d / cae).  _owner remembers which nn.Module bound a
+        # slot last, so a model whose own cache looks valid still re-binds after ANOTHER model of its class used the slot
+        # (two live CNN2D instances used alternately).  _train_gen counts train-mode forwards per slot: a backward whose
+        # forward is no longer the slot's latest would read another forward's saved activations and raises instead.
+        self._owner = {}
+        self._train_gen = {}
 
     @classmethod
     def get(cls, device) -> "Context":
@@ -130,6 +136,31 @@ class Context:
         if idx not in cls._by_device:
             cls._by_device[idx] = Context(torch.device("cuda", idx))
         return cls._by_device[idx]
+
+    def owner_changed(self, kind: str, model) -> bool:
+        """Claim the ctx's `kind` weight slot for `model`; True when another model held it (caches must be rebuilt)."""
+        token = model.__dict__.get("_ctx_token")
+        if token is None:
+            token = model.__dict__["_ctx_token"] = object()
+        changed = self._owner.get(kind) is not token
+        self._owner[kind] = token
+        return changed
+
+    def next_train_gen(self, kind: str) -> int:
+        g = self._train_gen.get(kind, 0) + 1
+        self._train_gen[kind] = g
+        return g
+
+    def check_train_gen(self, kind: str, gen: int, model=None):
+        if model is not None and self._owner.get(kind) is not model.__dict__.get("_ctx_token"):
+            raise RuntimeError(
+                f"backward of a {kind} train-mode forward after ANOTHER {kind} model used this device's weight slot: "
+                "run backward before calling a second model of the same class")
+        if self._train_gen.get(kind) != gen:
+            raise RuntimeError(
+                f"backward of a {kind} train-mode forward that is no longer the latest one on this device: the saved "
+                "activations live in one workspace per model class and were overwritten by a later train-mode forward. "
+                "Call backward before the next forward (losses of two forwards cannot be summed on this path).")
 
     def use_current_stream(self):
         s = torch.cuda.current_stream(self.index).cuda_stream

@@ -89,7 +89,8 @@ class FusedAugment:
 
     def __init__(self, spec_augment=False, time_mask_ratio=0.2, feature_mask=False, feature_mask_ratio=0.1,
                  time_shift=False, time_shift_ratio=0.1, channel_drop=False, channel_drop_prob=0.1,
-                 gaussian_jitter=False, gaussian_jitter_std=0.01, out_dtype=None, seed=None):
+                 gaussian_jitter=False, gaussian_jitter_std=0.01, out_dtype=None, seed=None, rng_device=None):
+        self.rng_device = rng_device      # where the keep mask is drawn: None = the batch's device (src/augmentation.py:52), 'cpu' = the host generator
         self.spec, self.tm_ratio = bool(spec_augment), float(time_mask_ratio)
         self.fmask, self.fm_ratio = bool(feature_mask), float(feature_mask_ratio)
         self.shift, self.shift_ratio = bool(time_shift), float(time_shift_ratio)
@@ -112,7 +113,8 @@ class FusedAugment:
             shift = random.randint(-limit, limit)
         keep = None
         if self.cdrop and self.cdrop_p > 0:
-            keep = (torch.rand((1, 1, F), device=device) >= self.cdrop_p).to(torch.float32).reshape(F).contiguous()
+            keep = (torch.rand((1, 1, F), device=self.rng_device or device) >= self.cdrop_p).to(torch.float32).reshape(F)
+            keep = keep.to(device).contiguous()
         return shift, keep, tm[0], tm[1], fm[0], fm[1]
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

@@ -29,6 +29,24 @@ def make_loader(features_path, labels_path, batch_size=32, num_workers=2, shuffl
                       num_workers=num_workers)
 
 
+def train_shard_indices(perm: torch.Tensor, batch_size: int, rank: int = 0, world: int = 1) -> torch.Tensor:
+    """Sample indices of `rank` for one data-parallel training epoch over the permutation `perm`.
+
+    Global batch g is perm[g*world*bs : (g+1)*world*bs]; rank r takes rows [r*bs, (r+1)*bs) of it.  With world > 1 the
+    permutation is padded by wrap-around to a multiple of world*bs (DistributedSampler semantics), so EVERY rank runs
+    the same number of steps with the same local batch size: one all-reduce per step on every rank (no hang on a short
+    last shard) and the 1/world gradient scale is exact.  world == 1 keeps the reference's ragged last batch
+    (src/train.py:61: the DataLoader's final short batch)."""
+    n = perm.numel()
+    if world <= 1 or n == 0:
+        return perm
+    gb = world * batch_size
+    total = -(-n // gb) * gb
+    reps = -(-total // n)
+    ext = perm.repeat(reps)[:total] if reps > 1 else perm
+    return ext.view(-1, world, batch_size)[:, rank].reshape(-1)
+
+
 class FlatBatcher:
     """Iterate (features [b,180,321] on `device`, labels [b] on `device` or None) over a stacked dataset.
 

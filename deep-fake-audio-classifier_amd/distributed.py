@@ -15,16 +15,21 @@ import numpy as np
 import torch
 
 
-def init(backend: str | None = None, device: torch.device | None = None):
+def init(backend: str | None = None, device: torch.device | None = None, force_group: bool = False):
     """Initialise the default process group from torchrun's environment (RANK/WORLD_SIZE/MASTER_*).
-    Returns (rank, world).  A single process (no WORLD_SIZE) needs no group: (0, 1)."""
+    Returns (rank, world).  A single process (no WORLD_SIZE) needs no group: (0, 1), unless force_group asks for a
+    one-rank group (used to exercise the RCCL code path on a one-GPU box).  Backend: the argument, else the environment
+    variable DFA_DIST_BACKEND, else "nccl" (= RCCL on ROCm) when a GPU is present, else "gloo"."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not force_group:
         return 0, 1
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        backend = backend or os.environ.get("DFA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend=backend, **kwargs)
     return dist.get_rank(), dist.get_world_size()
@@ -61,3 +66,45 @@ def broadcast_parameters_(flat_params: torch.Tensor, src: int = 0, group=None) -
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_params, src=src, group=group)
     return flat_params
+
+
+def average_tensors_(tensors, group=None):
+    """Replace every tensor by its mean over ranks with ONE all-reduce of a flat copy (BatchNorm running statistics
+    before a dev evaluation / checkpoint: they are updated from rank-local batches and drift apart otherwise)."""
+    import torch.distributed as dist
+    tensors = list(tensors)
+    if not tensors or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            k = t.numel()
+            t.copy_(flat[off:off + k].view_as(t))
+            off += k
+    return tensors
+
+
+def bn_running_stats(model):
+    """The running_mean / running_var buffers of a dfa_amd model, in module order."""
+    return [b for name, b in model.named_buffers() if name.endswith("running_mean") or name.endswith("running_var")]
+
+
+def rank_seed(seed: int, rank: int) -> int:
+    """A per-rank 64-bit Philox key derived from the run seed (dropout masks and jitter noise must differ between the
+    ranks of a data-parallel step; the mask SPANS stay a per-global-batch draw like the reference's per-batch draw)."""
+    return (int(seed) + 0x9E3779B97F4A7C15 * (int(rank) + 1)) & 0xFFFFFFFFFFFFFFFF if rank else int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def mean_scalar(value, device=None, group=None):
+    """Mean over ranks of a python float (None stays None): the epoch's training loss, so that every rank holds the same
+    number when it feeds the best-checkpoint tie-break."""
+    import torch.distributed as dist
+    if value is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    use_cuda = dist.get_backend(group) == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if use_cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)

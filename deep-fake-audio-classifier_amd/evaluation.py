@@ -97,6 +97,34 @@ def evaluate(model, dataloader, criterion=None, device="cuda", apply_sigmoid=Fal
     return {"avg_loss": avg_loss, "eer": eer, "threshold": threshold}, scores, labels
 
 
+def evaluate_sharded(model, features: torch.Tensor, labels: torch.Tensor, criterion=None, device="cuda",
+                     apply_sigmoid: bool = False, swap_tf: bool = True, batch_size: int = 32, rank: int = 0,
+                     world: int = 1, input_dtype=None):
+    """`evaluate` for data-parallel runs ("dev evaluation inside training = sharded inference +
+    gather"): rank r scores the contiguous utterance range [r*ceil(N/world), ...) of the stacked set, the per-rank
+    logit vectors are gathered in rank order, and every rank computes the SAME loss / EER from the same gathered
+    vector -- so best-checkpoint and early-stop decisions cannot diverge between ranks.  No data-path collective."""
+    from . import distributed as dfa_dist
+    from .dataloaders import FlatBatcher
+    model.eval()
+    chunks = []
+    with torch.no_grad():
+        for feats, _ in FlatBatcher(features, None, batch_size, device=device, rank=rank, world=world, dtype=input_dtype):
+            x = feats.transpose(1, 2) if swap_tf else feats
+            chunks.append(model(x).squeeze(-1).detach())
+    local = torch.cat(chunks).double().cpu().numpy() if chunks else np.zeros(0)
+    logits = dfa_dist.gather_scores(local)
+    y = labels.double().cpu().numpy()
+    if len(logits) != len(y):
+        raise ValueError(f"gathered {len(logits)} scores for {len(y)} labels")
+    avg_loss = None
+    if criterion is not None and len(y):
+        avg_loss = float(criterion(torch.from_numpy(logits).float(), torch.from_numpy(y).float()).item())
+    scores = (1.0 / (1.0 + np.exp(-logits))) if apply_sigmoid else logits
+    eer, threshold = calculate_eer(scores.tolist(), y.tolist()) if len(y) else (None, None)
+    return {"avg_loss": avg_loss, "eer": eer, "threshold": threshold}, scores.tolist(), y.tolist()
+
+
 def verify_uttid_alignment(features_path: str, labels_path: str) -> None:
     """ValueError unless both pickles carry 'uttid' and describe the same utterances (src/evaluation.py:107-124)."""
     feats = pd.read_pickle(features_path)

@@ -70,7 +70,8 @@ class ConvAutoencoder(nn.Module):
                 raise RuntimeError("ConvAutoencoder parameters must be contiguous float32 tensors on the GPU "
                                    "(call model.to('cuda')); dfa_amd has no CPU path")
         sig = (ctx.index, self.precision, tensors_signature(ts))
-        if sig == self._prepared:
+        stale = ctx.owner_changed("cae", self)      # another model of this class used the ctx's weight slot
+        if sig == self._prepared and not stale:
             return
         arr = _lib.ptr_array([t.detach() for t in ts])
         _lib.check(ctx.handle, ctx.lib.dfa_cae_set_params(ctx.handle, arr, len(ts), self.base_channels))

@@ -48,7 +48,8 @@ class CNN1D(nn.Module):
                 raise RuntimeError("CNN1D parameters must be contiguous float32 tensors on the GPU "
                                    "(call model.to('cuda')); dfa_amd has no CPU path")
         sig = (ctx.index, tensors_signature(ts))
-        if sig == self._prepared:
+        stale = ctx.owner_changed("cnn1d", self)      # another model of this class used the ctx's weight slot
+        if sig == self._prepared and not stale:
             return
         arr = _lib.ptr_array([t.detach() for t in ts])
         _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_set_params(ctx.handle, arr, len(ts), self.in_features,

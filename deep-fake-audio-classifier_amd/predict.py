@@ -79,6 +79,40 @@ def write_predictions(uttids, scores, out_path: str) -> pd.DataFrame:
     return df
 
 
+def build_submission(features_df: pd.DataFrame, prediction_df: pd.DataFrame, student_id: str, first_name: str,
+                     last_name: str, nickname: str) -> dict:
+    """The submission dict of scripts/generate_submission.py:17-48, with the same checks and error messages:
+    {student_id, first_name, last_name, nickname, predictions: DataFrame{uttid, predictions float64}}."""
+    import numpy as np
+    if len(prediction_df.columns) != 2:
+        raise ValueError("prediction.pkl must have exactly 2 columns")
+    if "uttid" not in prediction_df.columns or "predictions" not in prediction_df.columns:
+        raise ValueError("prediction.pkl must have 'uttid' and 'predictions' columns")
+    if "uttid" not in features_df.columns:
+        raise ValueError("features.pkl must have 'uttid' column")
+    if set(features_df["uttid"].values) != set(prediction_df["uttid"].values):
+        raise ValueError("uttid mismatch between features.pkl and prediction.pkl")
+    if not all(isinstance(x, (float, np.floating)) for x in prediction_df["predictions"].values):
+        prediction_df = prediction_df.copy()
+        prediction_df["predictions"] = prediction_df["predictions"].astype(np.float64)
+    return {"student_id": student_id, "first_name": first_name, "last_name": last_name, "nickname": nickname,
+            "predictions": prediction_df}
+
+
+def write_submission(features_path: str, prediction_path: str, student_id: str, first_name: str, last_name: str,
+                     nickname: str, out_dir: str = ".") -> str:
+    """Counterpart of `python scripts/generate_submission.py features.pkl prediction.pkl ID First Last Nick`
+    (:38-53): pickles the dict as <ID>-<First>-<Last>-<Nick>.pkl and returns the path."""
+    import os
+    import pickle
+    result = build_submission(pd.read_pickle(features_path), pd.read_pickle(prediction_path), student_id, first_name,
+                              last_name, nickname)
+    path = os.path.join(out_dir, f"{student_id}-{first_name}-{last_name}-{nickname}.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump(result, fh)
+    return path
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Generate prediction.pkl from a model checkpoint (MI355X HIP path).")
     p.add_argument("--features", required=True, help="Path to features.pkl")

@@ -21,9 +21,9 @@ from torch import nn
 
 from . import distributed as dfa_dist
 from .augmentation import FusedAugment, channel_drop, compose, gaussian_jitter, spec_augment, time_shift
-from .dataloaders import FlatBatcher, make_loader
+from .dataloaders import FlatBatcher, make_loader, train_shard_indices
 from .dataset import AudioDeepfakeDataset
-from .evaluation import evaluate
+from .evaluation import evaluate, evaluate_sharded
 from .model import CNN2D
 from .training import save_checkpoint
 
@@ -174,45 +174,69 @@ def main(argv=None):
 
     if args.model == "cnn1d":
         from .model_cnn1d import CNN1D
-        if args.native or world > 1:
-            raise ValueError("--native / multi-GPU training is implemented for cnn2d; cnn1d trains through the autograd bridge")
         model = CNN1D(in_features=args.in_features, dropout=args.dropout).to(device)
     else:
         model = CNN2D(in_features=args.in_features, dropout=args.dropout, precision=args.precision).to(device)
+    # dropout masks (and the jitter noise below) are Philox streams keyed by the run seed AND the rank: the ranks of one
+    # data-parallel step must not draw identical masks
+    model._drop_seed = dfa_dist.rank_seed(args.seed if args.seed else torch.initial_seed(), rank)
     weight_decay = args.weight_decay if args.weight_decay > 0 else 0.01      # AdamW default of src/train.py:321-325
     criterion = make_criterion(args.label_smoothing)
     augment_fn = build_augment_fn(args, fused=(device.type == "cuda"))   # batches are on the GPU when it is applied
+    if isinstance(augment_fn, FusedAugment):
+        augment_fn.seed = dfa_dist.rank_seed(augment_fn.seed, rank)
 
-    if args.native or world > 1:
-        from .training.train_step import NativeTrainer
-        trainer = NativeTrainer(model, lr=args.lr, weight_decay=weight_decay, label_smoothing=args.label_smoothing)
+    flat_mode = args.native or world > 1          # one flat parameter / gradient buffer, one all-reduce per step
+    trainer = None
+    if flat_mode:
+        from .training.train_step import FlatTrainer, NativeTrainer
+        if args.model == "cnn2d":
+            trainer = NativeTrainer(model, lr=args.lr, weight_decay=weight_decay, label_smoothing=args.label_smoothing)
+        else:                                     # CNN1D: autograd bridge + flat-buffer exchange (195,204-byte all-reduce)
+            trainer = FlatTrainer(model, lr=args.lr, weight_decay=weight_decay)
         dfa_dist.broadcast_parameters_(trainer.flat_p)
+        dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
         feats, labels = AudioDeepfakeDataset(args.train_features, args.train_labels).stacked(pin=True)
-        optimizer = _NativeOptimizerView(trainer)
+        dev_feats, dev_labels = AudioDeepfakeDataset(args.dev_features, args.dev_labels).stacked(pin=True)
+        optimizer = trainer
     else:
-        trainer = None
         optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=weight_decay)
         train_loader = make_loader(args.train_features, args.train_labels, batch_size=args.batch_size,
                                    num_workers=args.num_workers, shuffle=True)
-    dev_loader = make_loader(args.dev_features, args.dev_labels, batch_size=args.batch_size,
-                             num_workers=args.num_workers, shuffle=False)
+        dev_loader = make_loader(args.dev_features, args.dev_labels, batch_size=args.batch_size,
+                                 num_workers=args.num_workers, shuffle=False)
     scheduler = None
-    if args.lr_scheduler == "plateau" and trainer is None:
-        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
-            optimizer, mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience,
-            threshold=args.lr_scheduler_threshold, min_lr=args.lr_scheduler_min_lr)
+    if args.lr_scheduler == "plateau":            # src/train.py:332-341
+        kw = dict(mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience,
+                  threshold=args.lr_scheduler_threshold, min_lr=args.lr_scheduler_min_lr)
+        scheduler = trainer.plateau_scheduler(**kw) if trainer is not None else \
+            torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, **kw)
 
     best_eer = best_train = best_dev = None
     no_improve, last_epoch = 0, 0
     for epoch in range(1, args.epochs + 1):
-        if trainer is not None:
+        if flat_mode:
+            # every rank draws the SAME permutation and takes its rows of every global batch: equal step counts and equal
+            # local batch sizes on all ranks (dataloaders.train_shard_indices)
             perm = torch.randperm(feats.shape[0], generator=torch.Generator().manual_seed(args.seed + epoch))
-            batcher = FlatBatcher(feats[perm], labels[perm], args.batch_size, device=device, rank=rank, world=world)
-            train_loss = train_one_epoch_native(trainer, batcher, augment_fn, args.swap_tf)
+            idx = train_shard_indices(perm, args.batch_size, rank, world)
+            batcher = FlatBatcher(feats[idx], labels[idx], args.batch_size, device=device)
+            if isinstance(trainer, FlatTrainer):
+                train_loss = train_one_epoch(model, batcher, criterion, trainer, device=device, augment_fn=augment_fn,
+                                             swap_tf=args.swap_tf)
+            else:
+                train_loss = train_one_epoch_native(trainer, batcher, augment_fn, args.swap_tf)
+            train_loss = dfa_dist.mean_scalar(train_loss, device)
+            # BatchNorm running statistics come from rank-local batches: average them so that every rank evaluates (and
+            # rank 0 checkpoints) the same model
+            dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
+            model._prepared = None
+            metrics, _, _ = evaluate_sharded(model, dev_feats, dev_labels, criterion=criterion, device=device,
+                                             swap_tf=args.swap_tf, batch_size=args.batch_size, rank=rank, world=world)
         else:
             train_loss = train_one_epoch(model, train_loader, criterion, optimizer, device=device,
                                          augment_fn=augment_fn, swap_tf=args.swap_tf)
-        metrics, _, _ = evaluate(model, dev_loader, criterion=criterion, device=device, swap_tf=args.swap_tf)
+            metrics, _, _ = evaluate(model, dev_loader, criterion=criterion, device=device, swap_tf=args.swap_tf)
         eer, dev_loss = metrics["eer"], metrics["avg_loss"]
         is_best = False
         if eer is not None:
@@ -226,7 +250,7 @@ def main(argv=None):
         if scheduler is not None:
             metric = dev_loss if args.lr_scheduler_metric == "dev_loss" else eer
             if metric is not None:
-                scheduler.step(metric)
+                scheduler.step(metric)             # the metric is identical on every rank (gathered scores)
         if rank == 0:
             print(f"epoch {epoch}: train_loss={train_loss:.6f} dev_loss={dev_loss:.6f} dev_eer={eer:.6f}"
                   + ("  *best*" if is_best else ""))
@@ -234,29 +258,9 @@ def main(argv=None):
                 save_checkpoint(model, optimizer, epoch, args, best_path, scheduler=scheduler)
         last_epoch = epoch
         if args.early_stop and no_improve >= args.early_stop:
-            break
+            break                                  # same decision on every rank: it depends on gathered metrics only
     if rank == 0:
         save_checkpoint(model, optimizer, last_epoch, args, last_path, scheduler=scheduler)
-
-
-class _NativeOptimizerView:
-    """state_dict() of the fused optimiser in torch.optim.AdamW's format, so checkpoints stay interchangeable."""
-
-    def __init__(self, trainer):
-        self.t = trainer
-
-    def state_dict(self):
-        t, state, off = self.t, {}, 0
-        for i, p in enumerate(t.model.parameters()):
-            k = p.numel()
-            state[i] = {"step": torch.tensor(float(t.step_count)),
-                        "exp_avg": t.exp_avg[off:off + k].view_as(p).clone(),
-                        "exp_avg_sq": t.exp_avg_sq[off:off + k].view_as(p).clone()}
-            off += k
-        group = {"lr": t.lr, "betas": t.betas, "eps": t.eps, "weight_decay": t.wd, "amsgrad": False,
-                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": list(range(len(state)))}
-        return {"state": state, "param_groups": [group]}
 
 
 if __name__ == "__main__":

@@ -15,6 +15,8 @@ import torch
 from torch import nn
 from torch.utils.data import DataLoader
 
+from . import distributed as dfa_dist
+from .dataloaders import train_shard_indices
 from .dataset_cae import BonafideDataset, FeatureNormalizer, build_normalizer
 from .model_cae import ConvAutoencoder
 from .training import save_checkpoint
@@ -49,6 +51,26 @@ def validate_reconstruction(model, dataloader, device="cuda"):
     return (float(total.item()) / count) if count else None
 
 
+@torch.no_grad()
+def validate_reconstruction_sharded(model, dataset, batch_size, num_workers, device, rank, world):
+    """validate_reconstruction over this rank's contiguous shard of `dataset`, then ONE all-reduce of (sum, count): every
+    rank returns the same validation MSE, so scheduler / best / early-stop decisions agree across ranks."""
+    import torch.distributed as dist
+    from torch.utils.data import Subset
+    lo, hi = dfa_dist.shard_range(len(dataset), rank, world)
+    loader = DataLoader(Subset(dataset, range(lo, hi)), batch_size=batch_size, shuffle=False, num_workers=num_workers)
+    model.eval()
+    total = torch.zeros(2, dtype=torch.float64, device=device)
+    for x in loader:
+        total[0] += model.score(x.to(device, non_blocking=True)).double().sum()
+        total[1] += x.size(0)
+    if world > 1:
+        t = total if dist.get_backend() == "nccl" else total.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = t
+    return float(total[0].item() / total[1].item()) if float(total[1].item()) > 0 else None
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Train the convolutional auto-encoder for anomaly detection (MI355X).")
     p.add_argument("--train-features", default="data/train/features.pkl")
@@ -79,42 +101,69 @@ def main(argv=None):
     random.seed(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    device = args.device
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local_rank) if str(args.device).startswith("cuda") else torch.device(args.device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    rank, world = dfa_dist.init(device=device)
     ckpt_dir = os.path.join(args.checkpoint_dir, args.run_name)
     os.makedirs(ckpt_dir, exist_ok=True)
     best_path, last_path = os.path.join(ckpt_dir, "cae_best.pt"), os.path.join(ckpt_dir, "cae_last.pt")
     if args.normalizer_path and os.path.exists(args.normalizer_path):
         normalizer = FeatureNormalizer.load(args.normalizer_path)
     else:
-        normalizer = build_normalizer(args.train_features, args.train_labels)
-        normalizer.save(os.path.join(ckpt_dir, "normalizer.pt"))
+        normalizer = build_normalizer(args.train_features, args.train_labels)   # deterministic: identical on every rank
+        if rank == 0:
+            normalizer.save(os.path.join(ckpt_dir, "normalizer.pt"))
     train_ds = BonafideDataset(args.train_features, args.train_labels, normalizer=normalizer, swap_tf=True)
     val_ds = BonafideDataset(args.dev_features, args.dev_labels, normalizer=normalizer, swap_tf=True)
-    train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
-    val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
 
     model = ConvAutoencoder(base_channels=args.base_channels, precision=args.precision).to(device)
     criterion = nn.MSELoss()
-    optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
-    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
-        optimizer, mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience, threshold=1e-4,
-        min_lr=args.lr_scheduler_min_lr)
+    sched_kw = dict(mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience, threshold=1e-4,
+                    min_lr=args.lr_scheduler_min_lr)
+    if world > 1:
+        # data parallel (src/train_cae.py:58-82 on every rank's shard): one flat 2,246,532-byte gradient all-reduce per
+        # step, fused AdamW, equal step counts on every rank
+        from .training.train_step import FlatTrainer
+        optimizer = FlatTrainer(model, lr=args.lr, weight_decay=args.weight_decay)
+        dfa_dist.broadcast_parameters_(optimizer.flat_p)
+        scheduler = optimizer.plateau_scheduler(**sched_kw)
+    else:
+        optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, **sched_kw)
+        train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
+        val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
     best, no_improve, last_epoch = None, 0, 0
     for epoch in range(1, args.epochs + 1):
-        train_loss = train_one_epoch(model, train_loader, criterion, optimizer, device)
-        val_mse = validate_reconstruction(model, val_loader, device)
+        if world > 1:
+            from torch.utils.data import Subset
+            perm = torch.randperm(len(train_ds), generator=torch.Generator().manual_seed(args.seed + epoch))
+            idx = train_shard_indices(perm, args.batch_size, rank, world)
+            train_loader = DataLoader(Subset(train_ds, idx.tolist()), batch_size=args.batch_size, shuffle=False,
+                                      num_workers=args.num_workers)
+            train_loss = dfa_dist.mean_scalar(train_one_epoch(model, train_loader, criterion, optimizer, device), device)
+            dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
+            model._prepared = None
+            val_mse = validate_reconstruction_sharded(model, val_ds, args.batch_size, args.num_workers, device, rank, world)
+        else:
+            train_loss = train_one_epoch(model, train_loader, criterion, optimizer, device)
+            val_mse = validate_reconstruction(model, val_loader, device)
         scheduler.step(val_mse)
         is_best = best is None or val_mse < best
-        print(f"epoch {epoch}: train_mse={train_loss:.6f} val_mse={val_mse:.6f}" + ("  *best*" if is_best else ""))
+        if rank == 0:
+            print(f"epoch {epoch}: train_mse={train_loss:.6f} val_mse={val_mse:.6f}" + ("  *best*" if is_best else ""))
         if is_best:
             best, no_improve = val_mse, 0
-            save_checkpoint(model, optimizer, epoch, args, best_path, scheduler=scheduler)
+            if rank == 0:
+                save_checkpoint(model, optimizer, epoch, args, best_path, scheduler=scheduler)
         else:
             no_improve += 1
         last_epoch = epoch
         if args.early_stop and no_improve >= args.early_stop:
             break
-    save_checkpoint(model, optimizer, last_epoch, args, last_path, scheduler=scheduler)
+    if rank == 0:
+        save_checkpoint(model, optimizer, last_epoch, args, last_path, scheduler=scheduler)
 
 
 if __name__ == "__main__":

@@ -35,7 +35,8 @@ def _bind_cnn2d(model, ctx):
         if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("CNN2D parameters must be contiguous float32 tensors on the GPU (model.to('cuda'))")
     sig = (ctx.index, tuple(t.data_ptr() for t in ts))
-    if getattr(model, "_bound", None) != sig:
+    stale = ctx.owner_changed("cnn2d", model)
+    if getattr(model, "_bound", None) != sig or stale:
         arr = _lib.ptr_array([t.detach() for t in ts])
         _lib.check(ctx.handle, ctx.lib.dfa_cnn2d_set_params(ctx.handle, arr, len(ts), model.in_features,
                                                             model.base_channels))
@@ -50,7 +51,7 @@ def _next_dropout_offset(model, n_elems):
 
 
 def cnn2d_forward_train_raw(model, x, update_running_stats=True):
-    """Run dfa_cnn2d_forward_train; returns (logits[B,1], ctx, workspace)."""
+    """Run dfa_cnn2d_forward_train; returns (logits[B,1], ctx, workspace).  Stamps model._train_gen."""
     if x.device.type != "cuda":
         raise RuntimeError("dfa_amd.CNN2D runs on the GPU only: move the input with .to('cuda')")
     B, T, F = x.shape
@@ -74,14 +75,19 @@ def cnn2d_forward_train_raw(model, x, update_running_stats=True):
             float(model.dropout), seed, offset, 0.1, int(update_running_stats), C.c_void_p(logits.data_ptr()), None,
             C.c_void_p(ws.data_ptr()), ws.numel())
         _lib.check(ctx.handle, code)
+        model._train_gen = ctx.next_train_gen("cnn2d")
+        model._train_shape = (B, T, F, prec, x.dtype)
         if update_running_stats:
             for i in model._BN_IDX:
                 model.conv[i].num_batches_tracked += 1
     return logits, ctx, ws
 
 
-def cnn2d_backward_raw(model, x, dlogits, grad_tensors, ctx, ws):
+def cnn2d_backward_raw(model, x, dlogits, grad_tensors, ctx, ws, gen=None):
     B, T, F = x.shape
+    ctx.check_train_gen("cnn2d", model._train_gen if gen is None else gen, model)
+    if (B, T, F, _lib.PRECISIONS[model.precision], x.dtype) != getattr(model, "_train_shape", None):
+        raise RuntimeError("backward called with a batch shape / precision / dtype other than its forward's")
     with torch.cuda.device(ctx.index):
         ctx.use_current_stream()
         arr = _lib.ptr_array(grad_tensors)
@@ -96,14 +102,14 @@ class Cnn2dTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(fctx, x, model, *params):
         logits, ctx, ws = cnn2d_forward_train_raw(model, x)
-        fctx.model, fctx.x, fctx.ctx, fctx.ws = model, x, ctx, ws
+        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, model._train_gen
         return logits
 
     @staticmethod
     def backward(fctx, dlogits):
         model = fctx.model
         grads = [torch.empty_like(p) for p in model.parameters()]
-        cnn2d_backward_raw(model, fctx.x, dlogits.contiguous().float(), grads, fctx.ctx, fctx.ws)
+        cnn2d_backward_raw(model, fctx.x, dlogits.contiguous().float(), grads, fctx.ctx, fctx.ws, fctx.gen)
         return (None, None, *grads)
 
 
@@ -119,7 +125,8 @@ def _bind_cnn1d(model, ctx):
         if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("CNN1D parameters must be contiguous float32 tensors on the GPU (model.to('cuda'))")
     sig = (ctx.index, tuple(t.data_ptr() for t in ts))
-    if getattr(model, "_bound", None) != sig:
+    stale = ctx.owner_changed("cnn1d", model)
+    if getattr(model, "_bound", None) != sig or stale:
         arr = _lib.ptr_array([t.detach() for t in ts])
         _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_set_params(ctx.handle, arr, len(ts), model.in_features,
                                                             model.base_channels))
@@ -152,12 +159,13 @@ class Cnn1dTrainFunction(torch.autograd.Function):
                 offset, 0.1, 1, C.c_void_p(logits.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel()))
             for i in model._BN_IDX:
                 model.conv[i].num_batches_tracked += 1
-        fctx.model, fctx.x, fctx.ctx, fctx.ws = model, x, ctx, ws
+        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, ctx.next_train_gen("cnn1d")
         return logits
 
     @staticmethod
     def backward(fctx, dlogits):
         model, x, ctx, ws = fctx.model, fctx.x, fctx.ctx, fctx.ws
+        ctx.check_train_gen("cnn1d", fctx.gen, model)
         grads = [torch.empty_like(p) for p in model.parameters()]
         B, T, F = x.shape
         d = dlogits.contiguous().float()
@@ -180,7 +188,8 @@ def _bind_cae(model, ctx):
         if t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("ConvAutoencoder parameters must be contiguous float32 tensors on the GPU")
     sig = (ctx.index, tuple(t.data_ptr() for t in ts))
-    if getattr(model, "_bound", None) != sig:
+    stale = ctx.owner_changed("cae", model)
+    if getattr(model, "_bound", None) != sig or stale:
         arr = _lib.ptr_array([t.detach() for t in ts])
         _lib.check(ctx.handle, ctx.lib.dfa_cae_set_params(ctx.handle, arr, len(ts), model.base_channels))
         model._bound = sig
@@ -217,13 +226,14 @@ class CaeTrainFunction(torch.autograd.Function):
             for _, bi in model._DEC:
                 if bi is not None:
                     model.decoder[bi].num_batches_tracked += 1
-        fctx.model, fctx.x, fctx.ctx, fctx.ws = model, x, ctx, ws
+        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, ctx.next_train_gen("cae")
         fctx.mark_non_differentiable(latent)
         return recon, latent
 
     @staticmethod
     def backward(fctx, drecon, _dlatent):
         model, x, ctx, ws = fctx.model, fctx.x, fctx.ctx, fctx.ws
+        ctx.check_train_gen("cae", fctx.gen, model)
         grads = [torch.empty_like(p) for p in model.parameters()]
         B, T, F = x.shape
         d = drecon.contiguous().float()
@@ -240,23 +250,18 @@ def cae_train_forward(model, x):
     return CaeTrainFunction.apply(x, model, *model.parameters())
 
 
-class NativeTrainer:
-    """Whole CNN2D training step on the C ABI: forward_train -> BCE(smoothed) -> backward -> all-reduce -> fused AdamW.
+class _FlatAdamW:
+    """Parameters re-homed into ONE flat fp32 buffer (each nn.Parameter becomes a view), gradients in ONE flat buffer,
+    AdamW moments alongside: the data-parallel exchange is a single all-reduce of `flat_g` and the update a single
+    fused kernel (dfa_adamw_step) whatever the model (464,644 B CNN2D, 195,204 B CNN1D, 2,246,532 B auto-encoder)."""
 
-    Parameters are re-homed into ONE flat fp32 buffer (each nn.Parameter becomes a view), gradients are produced into
-    ONE flat buffer, so data-parallel training needs a single all-reduce of 464,644 bytes per step."""
-
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, label_smoothing=0.0,
-                 process_group=None):
-        if not (0.0 <= label_smoothing < 0.5):
-            raise ValueError("--label-smoothing must be in [0, 0.5)")          # src/train.py:308-309
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None):
         self.model, self.lr, self.betas, self.eps, self.wd = model, lr, betas, eps, weight_decay
-        self.label_smoothing = label_smoothing
         self.pg = process_group
         params = list(model.parameters())
         dev = params[0].device
         if dev.type != "cuda":
-            raise RuntimeError("NativeTrainer needs the model on the GPU")
+            raise RuntimeError(f"{type(self).__name__} needs the model on the GPU")
         n = sum(p.numel() for p in params)
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -270,13 +275,104 @@ class NativeTrainer:
             self.grad_views.append(self.flat_g[off:off + k].view_as(p))
             off += k
         self.step_count = 0
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.dlogits = None
+        self._sched_opt = None
 
     @property
     def world(self):
         import torch.distributed as dist
         return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _exchange_and_update(self):
+        """SUM all-reduce of the flat gradient (RCCL over xGMI under the "nccl" backend), then fused AdamW with the
+        1/world scale folded in."""
+        world = self.world
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+        self.step_count += 1
+        ctx = _lib.Context.get(self.flat_p.device)
+        with torch.cuda.device(ctx.index):
+            ctx.use_current_stream()
+            _lib.check(ctx.handle, ctx.lib.dfa_adamw_step(
+                ctx.handle, C.c_void_p(self.flat_p.data_ptr()), C.c_void_p(self.flat_g.data_ptr()),
+                C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), self.flat_p.numel(),
+                float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+                self.step_count, 1.0 / world))
+        self.model._prepared = None
+
+    # ---- torch.optim.AdamW-compatible views (checkpoints stay interchangeable, src/training/checkpoint.py:42-71) ----
+    def state_dict(self):
+        state, off = {}, 0
+        for i, p in enumerate(self.model.parameters()):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + k].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(state)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        off = 0
+        for i, p in enumerate(self.model.parameters()):
+            k = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count = int(st["step"])
+            off += k
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+
+    def plateau_scheduler(self, **kw):
+        """torch's ReduceLROnPlateau driving THIS trainer's lr (src/train.py:332-341,520-525): the scheduler owns a
+        one-group stand-in optimiser whose lr is copied back after every scheduler.step(metric)."""
+        trainer = self
+        self._sched_opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=float(self.lr))
+
+        class _Plateau(torch.optim.lr_scheduler.ReduceLROnPlateau):
+            def step(self, metrics, *a, **k):
+                out = super().step(metrics, *a, **k)
+                trainer.lr = float(trainer._sched_opt.param_groups[0]["lr"])
+                return out
+        return _Plateau(self._sched_opt, **kw)
+
+
+class FlatTrainer(_FlatAdamW):
+    """Optimizer-shaped data-parallel engine for ANY dfa_amd model used through the autograd bridge (CNN1D with BCE,
+    the auto-encoder with MSELoss, src/train_cae.py:58-82): `zero_grad(); loss.backward(); step()`.  Every parameter's
+    .grad is a view of the flat gradient buffer, so autograd accumulates straight into the all-reduce payload."""
+
+    def __init__(self, model, **kw):
+        super().__init__(model, **kw)
+        for p, g in zip(model.parameters(), self.grad_views):
+            p.grad = g
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+        for p, g in zip(self.model.parameters(), self.grad_views):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def step(self):
+        self._exchange_and_update()
+
+
+class NativeTrainer(_FlatAdamW):
+    """Whole CNN2D training step on the C ABI: forward_train -> BCE(smoothed) -> backward -> all-reduce -> fused AdamW,
+    with no autograd graph."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, label_smoothing=0.0,
+                 process_group=None):
+        if not (0.0 <= label_smoothing < 0.5):
+            raise ValueError("--label-smoothing must be in [0, 0.5)")          # src/train.py:308-309
+        super().__init__(model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, process_group=process_group)
+        self.label_smoothing = label_smoothing
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
+        self.dlogits = None
 
     def step(self, x, y):
         """One optimisation step on batch (x[B,T,F], y[B]); returns the (device) loss scalar of this rank's batch."""
@@ -292,17 +388,5 @@ class NativeTrainer:
                 ctx.handle, C.c_void_p(logits.data_ptr()), C.c_void_p(y.data_ptr()), float(self.label_smoothing), B,
                 C.c_void_p(self.loss_buf.data_ptr()), C.c_void_p(self.dlogits.data_ptr())))
         cnn2d_backward_raw(model, x, self.dlogits, self.grad_views, ctx, ws)
-        world = self.world
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # RCCL on ROCm ("nccl" backend)
-        self.step_count += 1
-        with torch.cuda.device(ctx.index):
-            ctx.use_current_stream()
-            _lib.check(ctx.handle, ctx.lib.dfa_adamw_step(
-                ctx.handle, C.c_void_p(self.flat_p.data_ptr()), C.c_void_p(self.flat_g.data_ptr()),
-                C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()), self.flat_p.numel(),
-                float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
-                self.step_count, 1.0 / world))
-        model._prepared = None
+        self._exchange_and_update()
         return self.loss_buf

@@ -134,12 +134,78 @@ def _bn(sd, prefix, x, dtype):
                           sd[prefix + ".running_mean"], sd[prefix + ".running_var"], dtype=dtype)
 
 
-def cnn2d_forward(sd, x, return_intermediates=False, dtype=np.float32):
+def bf16_round(a):
+    """float32 -> bfloat16 (round to nearest even, the rounding of v_cvt_pk_bf16_f32 and torch's .to(bfloat16)) ->
+    float32.  Finite inputs only (the oracle never sees NaN/inf)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000))
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+def _fold_bn(sd, conv, bn):
+    """eval-mode BatchNorm folded into the preceding convolution, in fp32 and in the operation order of the product's
+    weight preparation: s = gamma / sqrt(var + eps); w' = w * s; b' = (b - mean) * s + beta  (src/model.py:15-16 etc.)."""
+    f = np.float32
+    s = (np.asarray(sd[bn + ".weight"], f) / np.sqrt(np.asarray(sd[bn + ".running_var"], f) + f(BN_EPS))).astype(f)
+    w = (np.asarray(sd[conv + ".weight"], f) * s[:, None, None, None]).astype(f)
+    b = ((np.asarray(sd[conv + ".bias"], f) - np.asarray(sd[bn + ".running_mean"], f)) * s + np.asarray(sd[bn + ".bias"], f)).astype(f)
+    return w, b
+
+
+def cnn2d_forward_emulated(sd, x, emulate="bf16", return_intermediates=False):
+    """CNN2D.forward (eval) restated with the ROUNDING POINTS of the product's bf16 storage mode (DFA_PREC_BF16, the
+    headline configuration), so the GPU result can be held to accumulation-order noise instead of a loose bf16 bound:
+
+      x -> bf16;  block 1: folded fp32 weights * 1/2 (pool factor) split into bf16 hi + lo, fp32 accumulate, ReLU, pool
+      add in fp32, a1 -> bf16;  block 2: (folded weights * 1/2) -> bf16, bias fp32, fp32 accumulate, ReLU, pool add,
+      a2 -> bf16;  block 3: folded weights -> bf16, fp32 accumulate, ReLU, mean over T and the classifier in fp32.
+
+    The sums are taken in float64 and rounded once to fp32 (the order-free limit of the kernels' fp32 accumulation).
+    emulate=None runs the same folded computation with every rounding replaced by the identity: that form must equal the
+    plain restatement `cnn2d_forward` (and the reference's goldens) to fp32 noise -- it pins the folding algebra.
+    Follows src/model.py:33-42 (stack :13-31); the rounding points are this project's, not the reference's."""
+    if emulate not in (None, "bf16"):
+        raise ValueError(f"emulate must be None or 'bf16', got {emulate!r}")
+    f, d = np.float32, np.float64
+    rnd = bf16_round if emulate == "bf16" else (lambda a: np.asarray(a, f))
+    w1, b1 = _fold_bn(sd, "conv.0", "conv.1")
+    w2, b2 = _fold_bn(sd, "conv.5", "conv.6")
+    w3, b3 = _fold_bn(sd, "conv.10", "conv.11")
+    half = f(0.5)
+    w1h = (half * w1).astype(f)
+    hi = rnd(w1h)
+    lo = rnd((w1h - hi).astype(f))
+    w1e = hi.astype(d) + lo.astype(d)                       # two exact bf16 x bf16 products per tap in the kernel
+    b1e = (half * b1).astype(f)
+    w2e = rnd((w2 * half).astype(f))
+    b2e = (b2 * half).astype(f)
+    w3e = rnd(w3)
+    xb = rnd(np.asarray(x, f))[:, None, :, :]
+
+    def pooled(z):                                          # relu(row 2q) + relu(row 2q+1) in fp32; 1/2 is in the weights
+        H = z.shape[2] // 2
+        z = relu(z[:, :, :2 * H]).astype(f)
+        return (z[:, :, 0::2] + z[:, :, 1::2]).astype(f)
+    a1 = rnd(pooled(conv2d_3x3(xb, w1e, b1e, d).astype(f)))
+    a2 = rnd(pooled(conv2d_3x3(a1, w2e, b2e, d).astype(f)))
+    a3 = relu(conv2d_3x3(a2, w3e, b3, d).astype(f))
+    H2 = a3.shape[2]
+    emb = (a3.sum(axis=2, dtype=d).astype(f) * f(1.0 / H2)).astype(f).reshape(a3.shape[0], -1)
+    logits = linear(emb, sd["classifier.weight"], sd["classifier.bias"], d).astype(f)
+    if return_intermediates:
+        return logits, {"a1": a1, "a2": a2, "a3": a3, "embedding": emb}
+    return logits
+
+
+def cnn2d_forward(sd, x, return_intermediates=False, dtype=np.float32, emulate=None):
     """CNN2D.forward in eval mode -- src/model.py:33-42 with the layer stack of :13-31.
 
     sd: state_dict as {key: ndarray} (keys conv.{0,1,5,6,10,11}.*, classifier.*).
     x:  [B,T,F] (any strides).  Returns logits [B,1] (and a dict of intermediates).
+    emulate="bf16": the same forward with the product's bf16-mode rounding points (cnn2d_forward_emulated).
     """
+    if emulate is not None:
+        return cnn2d_forward_emulated(sd, x, emulate, return_intermediates)
     h = np.asarray(x, dtype)[:, None, :, :]                                   # :34 unsqueeze(1)
     h = conv2d_3x3(h, sd["conv.0.weight"], sd["conv.0.bias"], dtype)           # :15
     h = relu(_bn(sd, "conv.1", h, dtype))                                      # :16-17

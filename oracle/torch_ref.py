@@ -60,3 +60,44 @@ def cae_forward(sd, x):
     elif Tr > T:
         d = d[:, :, :T, :]
     return d.squeeze(1), latent
+
+
+def _bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@torch.no_grad()
+def cnn2d_forward_emulated(sd, x, emulate="bf16", return_embedding=False):
+    """torch twin of dfa_oracle.cnn2d_forward_emulated (same rounding points of the product's bf16 storage mode, float64
+    sums rounded once to fp32), fast enough for full-size batches.  emulate=None = the folded computation without rounding."""
+    if emulate not in (None, "bf16"):
+        raise ValueError(f"emulate must be None or 'bf16', got {emulate!r}")
+    rnd = _bf16r if emulate == "bf16" else (lambda t: t)
+    f64 = torch.float64
+
+    def fold(conv, bn):
+        s = _t(sd, bn + ".weight").float() / torch.sqrt(_t(sd, bn + ".running_var").float() + 1e-5)
+        w = _t(sd, conv + ".weight").float() * s[:, None, None, None]
+        b = (_t(sd, conv + ".bias").float() - _t(sd, bn + ".running_mean").float()) * s + _t(sd, bn + ".bias").float()
+        return w, b
+    (w1, b1), (w2, b2), (w3, b3) = fold("conv.0", "conv.1"), fold("conv.5", "conv.6"), fold("conv.10", "conv.11")
+    w1h = 0.5 * w1
+    hi = rnd(w1h)
+    lo = rnd(w1h - hi)
+    w1e, b1e = hi.to(f64) + lo.to(f64), (0.5 * b1)
+    w2e, b2e = rnd(w2 * 0.5), b2 * 0.5
+    w3e = rnd(w3)
+
+    def conv(h, w, b):
+        return F.conv2d(h.to(f64), w.to(f64), b.to(f64), padding=1).float()
+
+    def pooled(z):
+        H = z.shape[2] // 2
+        z = F.relu(z[:, :, :2 * H])
+        return z[:, :, 0::2] + z[:, :, 1::2]
+    a1 = rnd(pooled(conv(rnd(x.float()).unsqueeze(1), w1e, b1e)))
+    a2 = rnd(pooled(conv(a1, w2e, b2e)))
+    a3 = F.relu(conv(a2, w3e, b3))
+    emb = (a3.sum(dim=2, dtype=f64).float() * (1.0 / a3.shape[2])).flatten(1)
+    logits = F.linear(emb.to(f64), _t(sd, "classifier.weight").to(f64), _t(sd, "classifier.bias").to(f64)).float()
+    return (logits, emb) if return_embedding else logits

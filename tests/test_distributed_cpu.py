@@ -85,3 +85,94 @@ def test_augmentations_semantics():
     with pytest.raises(ValueError):
         from dfa_amd.train import make_criterion
         make_criterion(0.5)
+
+
+# ---- round 2: data-parallel robustness (unequal shard lengths hang the per-step all-reduce) --------------
+def test_train_shard_indices_equal_steps_and_batches():
+    from dfa_amd.dataloaders import train_shard_indices
+    for n, world, bs in ((2050, 8, 256), (1025, 8, 32), (7, 2, 4), (11, 2, 4), (64, 4, 16), (3, 8, 2)):
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(n))
+        shards = [train_shard_indices(perm, bs, r, world) for r in range(world)]
+        steps = {len(s) // bs for s in shards}
+        assert len(steps) == 1 and all(len(s) % bs == 0 for s in shards), (n, world, bs)   # same step count, full batches
+        allidx = torch.cat(shards)
+        assert set(allidx.tolist()) == set(range(n))                                       # every sample is seen
+        assert len(allidx) - n < world * bs                                                # wrap-around pad < one global batch
+        # global batch g = the ranks' g-th local batches = a contiguous run of the (padded) permutation
+        g0 = torch.cat([s[:bs] for s in shards])
+        assert torch.equal(g0, perm.repeat(-(-world * bs // n) + 1)[:world * bs])
+    perm = torch.randperm(10)
+    assert torch.equal(train_shard_indices(perm, 4, 0, 1), perm)                           # world 1: ragged tail kept
+
+
+class _StubClassifier(torch.nn.Module):
+    """CPU stand-in with the reference's call contract (x[B,T,F] -> [B,1]); the product model has no CPU path."""
+
+    def __init__(self):
+        super().__init__()
+        self.bn = torch.nn.BatchNorm1d(3)
+        self.lin = torch.nn.Linear(3, 1)
+
+    def forward(self, x):
+        return self.lin(self.bn(x.mean(dim=1)))
+
+
+def _worker_dp(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import dfa_amd  # noqa: F401
+    from dfa_amd import distributed as D
+    from dfa_amd.dataloaders import FlatBatcher, train_shard_indices
+    from dfa_amd.evaluation import evaluate_sharded
+    D.init(backend="gloo")
+    # N = 11 with world 2 x batch 4: ceil-sharding gave rank 0 two steps (6 samples) and rank 1 two steps (5) here, but e.g.
+    # N = 9 gave 2 vs 1 -> mismatched all-reduce counts -> hang.  Equal-step shards: same count on every rank.
+    for n in (9, 11):
+        feats = torch.arange(n, dtype=torch.float32).view(n, 1, 1).expand(n, 3, 2).contiguous()
+        labels = (torch.arange(n) % 2).float()
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+        idx = train_shard_indices(perm, 4, rank, world)
+        steps = 0
+        for fb, lb in FlatBatcher(feats[idx], labels[idx], 4, device="cpu"):
+            assert fb.shape[0] == 4                              # equal local batch sizes: the 1/world scale is exact
+            g = torch.full((10,), float(fb[:, 0, 0].sum()))
+            D.allreduce_flat_(g)                                 # one collective per step on every rank
+            steps += 1
+        counts = [None] * world
+        dist.all_gather_object(counts, steps)
+        assert len(set(counts)) == 1 and steps == -(-n // 8), counts
+    # BatchNorm running statistics: averaged before evaluation
+    torch.manual_seed(0)
+    model = _StubClassifier()
+    with torch.no_grad():
+        model.bn.running_mean.fill_(float(rank))
+        model.bn.running_var.fill_(1.0 + 2.0 * rank)
+    D.average_tensors_(D.bn_running_stats(model))
+    assert torch.allclose(model.bn.running_mean, torch.full((3,), 0.5)) and torch.allclose(model.bn.running_var, torch.full((3,), 2.0))
+    assert D.mean_scalar(float(rank + 1)) == 1.5 and D.mean_scalar(None) is None
+    assert D.rank_seed(7, 0) == 7 and D.rank_seed(7, 1) != D.rank_seed(7, 2) != 7
+    # sharded dev evaluation: every rank gets the metrics of the WHOLE set, identical to the unsharded evaluation
+    n = 13
+    g = torch.Generator().manual_seed(1)
+    dev = torch.randn(n, 3, 5, generator=g)                      # stored layout [N, F, T]
+    y = (torch.rand(n, generator=g) > 0.5).float()
+    crit = torch.nn.BCEWithLogitsLoss()
+    m_sh, s_sh, l_sh = evaluate_sharded(model, dev, y, criterion=crit, device="cpu", swap_tf=True, batch_size=4, rank=rank, world=world)
+    model.eval()
+    with torch.no_grad():
+        want = model(dev.transpose(1, 2)).squeeze(-1).double().numpy()
+    assert np.allclose(np.asarray(s_sh), want, atol=1e-6) and l_sh == y.tolist()
+    both = [None] * world
+    dist.all_gather_object(both, (m_sh["eer"], m_sh["avg_loss"], m_sh["threshold"]))
+    assert both[0] == both[1]                                    # same decision inputs on every rank
+    assert abs(m_sh["avg_loss"] - float(crit(torch.from_numpy(want).float(), y))) < 1e-6
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"dp_ok{rank}"), "w").write("ok")
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_data_parallel_robustness(tmp_path):
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_dp, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"dp_ok{r}") for r in range(world))

@@ -137,3 +137,54 @@ def test_torch_ref_matches_reference(golden):
     recon, latent = R.cae_forward(sd, torch.from_numpy(g["t321.x"]))
     np.testing.assert_allclose(recon.numpy(), g["t321.recon"], atol=2e-5, rtol=1e-5)
     np.testing.assert_allclose(latent.numpy(), g["t321.latent"], atol=2e-5, rtol=1e-5)
+
+
+# ---- round 2: the rounding-faithful bf16 oracle (emulate="bf16") ------------------------------------------------
+def test_bf16_round_is_round_to_nearest_even():
+    import torch
+    g = np.random.default_rng(0)
+    a = np.concatenate([g.normal(0, 3, 4096), g.normal(0, 1e-3, 512), [1.0, -1.0, 0.0, 1.00390625, 1.01171875,
+                        3.3895313892515355e38, 1e-38]]).astype(np.float32)
+    want = torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(O.bf16_round(a), want)
+    # ties go to even: 1 + 2^-8 is halfway between bf16(1.0) and bf16(1.0078125)
+    assert O.bf16_round(np.float32(1.00390625)) == np.float32(1.0)
+    assert O.bf16_round(np.float32(1.01171875)) == np.float32(1.015625)
+
+
+@pytest.mark.parametrize("tag", ["t64", "t7", "t16"])
+def test_emulated_oracle_without_rounding_equals_reference(golden, tag):
+    """emulate=None runs the folded-BN / pool-factor-in-the-weights computation of the product with every rounding
+    replaced by the identity: it must reproduce the reference's logits (pins the folding algebra of the bf16 oracle)."""
+    sd, g = golden("cnn2d_eval")
+    x = np.swapaxes(g[f"{tag}.x_stored"], 1, 2)
+    logits, inter = O.cnn2d_forward_emulated(sd, x, emulate=None, return_intermediates=True)
+    np.testing.assert_allclose(logits, g[f"{tag}.logits"], atol=2e-5, rtol=0)
+    if tag == "t16":
+        np.testing.assert_allclose(inter["a1"], g["t16.a1"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(inter["a2"], g["t16.a2"], atol=2e-5, rtol=1e-5)
+    else:
+        np.testing.assert_allclose(inter["embedding"], g[f"{tag}.embedding"], atol=1e-5, rtol=1e-5)
+
+
+def test_emulated_bf16_oracle_sits_at_bf16_distance_from_reference_and_matches_torch_twin(golden):
+    import torch
+    from oracle import torch_ref as R
+    sd, g = golden("cnn2d_eval")
+    for tag in ("t64", "t7"):
+        xs = g[f"{tag}.x_stored"]
+        x = np.swapaxes(xs, 1, 2)
+        got, inter = O.cnn2d_forward(sd, x, return_intermediates=True, emulate="bf16")
+        want = g[f"{tag}.logits"]
+        d = np.abs(got - want).max()
+        assert 1e-5 < d < 5e-2, d                      # bf16 storage noise: well above fp32 noise, well below 0.1
+        # every stored activation is exactly representable in bf16
+        for k in ("a1", "a2"):
+            assert np.array_equal(O.bf16_round(inter[k]), inter[k])
+        tw, emb = R.cnn2d_forward_emulated(sd, torch.from_numpy(xs).transpose(1, 2), "bf16", return_embedding=True)
+        # same rounding points, float64 sums: the two restatements may differ only where a float64 sum lands within one
+        # fp32 ulp of a bf16 rounding boundary
+        np.testing.assert_allclose(tw.numpy(), got, atol=2e-4, rtol=0)
+        np.testing.assert_allclose(emb.numpy(), inter["embedding"], atol=2e-4, rtol=1e-3)
+    tw0 = R.cnn2d_forward_emulated(sd, torch.from_numpy(g["t64.x_stored"]).transpose(1, 2), None)
+    np.testing.assert_allclose(tw0.numpy(), g["t64.logits"], atol=2e-5, rtol=0)
