@@ -22,8 +22,9 @@ pytestmark = pytest.mark.gpu
 TOL_F32 = 1e-4        # north_star: logits within 1e-4 in fp32
 # bf16 storage mode vs the rounding-faithful oracle: what remains is fp32 accumulation order plus the rare bf16
 # re-rounding of an activation whose fp32 value sits within an ulp of a rounding boundary.  Measured on MI355X
-# (tools/gpu_bf16_emu_probe.py): max |dlogit| 3e-4 at |logit| ~ 3..6 over the golden cases -> bound 1.5e-3 relative.
-TOL_BF16_EMU_REL = 1.5e-3
+# (tools/gpu_bf16_emu_probe.py, round 2): max |dlogit| 1.9e-5 / 1.4e-4 / 2.6e-4 on the golden T = 321 / 64 / 7 cases at
+# |logit| ~ 3, where the fp32 reference sits 1.7e-3 .. 9e-3 away -> bound 1e-3 relative to max(1, |logit|).
+TOL_BF16_EMU_REL = 1e-3
 
 
 def _model_from_sd(sd, precision="fp32"):
@@ -55,12 +56,14 @@ def test_cnn2d_bf16_mode_matches_rounding_faithful_oracle(golden, tag):
     scale = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(logits.cpu().numpy(), want, atol=TOL_BF16_EMU_REL * scale, rtol=0)
     np.testing.assert_allclose(emb.cpu().numpy(), inter["embedding"], atol=2e-3 * max(1.0, float(np.abs(inter["embedding"]).max())), rtol=0)
-    # a2 is stored in bf16 on both sides: elements are EQUAL except where an fp32 sum sat on a rounding boundary, and then
-    # they differ by one bf16 ulp (2^-8 relative) -- an indexing bug in a halo column cannot hide here
+    # a2 is stored in bf16 on both sides: elements are EQUAL except where an fp32 sum sat on a rounding boundary; then they
+    # differ by one bf16 ulp (2^-8 relative), plus -- where a re-rounded a1 element feeds a sum with cancellation -- a
+    # little more in absolute terms (2e-3 against an rms of 0.34).  An indexing bug in a halo column (differences of the
+    # order of the values, in whole columns) cannot hide here.
     ref_a2 = inter["a2"].transpose(0, 2, 3, 1)
     diff = np.abs(a2 - ref_a2)
-    assert float((diff > 0).mean()) < 0.02, float((diff > 0).mean())
-    assert np.all(diff <= 2.0 ** -7 * np.abs(ref_a2) + 1e-5)      # 1e-5: a sum that straddles the ReLU's zero
+    assert float((diff > 0).mean()) < 0.005, float((diff > 0).mean())
+    assert np.all(diff <= 2.0 ** -7 * np.abs(ref_a2) + 2e-3), float((diff - 2.0 ** -7 * np.abs(ref_a2)).max())
     # and the fp32 reference sits at bf16 distance (sanity: the oracle emulates, it does not replace, the reference)
     assert np.abs(logits.cpu().numpy() - g[f"{tag}.logits"]).max() < 0.05 * scale
 
