@@ -9,11 +9,17 @@ bf16 storage / fp32 accumulate) on N MI355X GPUs of one node, one process per GP
 A step = one pass of the hot path over one batch of 256 utterances per GPU, inputs already resident in HBM.
 Inference shards by utterance with no data-path collective, so N GPUs run N independent
 shards ("scaling": "weak"); the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the torch.distributed.run command above
+itself, as a child process, before anything in this process touches the GPU, and exits with the child's code.
 Rank 0 prints ONE JSON line.  Extra objects on it:
   roofline     -- the dominant kernel (block-3 MFMA conv): algorithmic FLOPs per launch / average launch duration
                   measured with HIP events on the launch stream during the timed steps, vs the dense MFMA peak
   cpu_baseline -- the CPU restatement of the reference path (oracle/torch_ref.py) timed on this host, rank 0, N=1
   fp32_parity  -- the same workload in the exact-fp32 parity mode (logits within 1e-4 of the reference)
+  train_step   -- BASELINE configs[2] on one GPU with its own roofline object (9,621,849,600 FLOP per utterance)
+  end_to_end   -- features.pkl on the host -> prediction.pkl (unpickle, H2D over PCIe, kernels, D2H, pickle) on the GPU
+                  path and (cpu_baseline.end_to_end) on the CPU restatement of src/predict.py, same file; plus the
+                  flat-file ingest rate (memmap -> pinned double-buffered H2D -> kernels)
 """
 import argparse
 import json
@@ -34,10 +40,18 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROA
 
 
 def pmc_traffic(prec):
-    """HBM bytes per launch of the block-3 kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json;
-    counters cannot be read from inside this process).  None if the summary is absent."""
+    """HBM bytes per launch of the block-3 kernel from the committed rocprofv3 PMC passes of this bench command
+    (profiles/r02_pmc_traffic.json, made by tools/rocpd_summary.py from separate --pmc runs; hardware counters cannot be
+    read from inside this process).  None if the summary is absent."""
     try:
-        blob = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        blob = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                blob = json.load(open(path))
+                break
+        if blob is None:
+            return None
     except (OSError, ValueError):
         return None
     tag = "conv3_m16_meant_kernel" if prec == "bf16" else "conv3x3_mfma_kernel<float, 64, 4"
@@ -57,6 +71,7 @@ def parse_args():
     p.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU per step")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    p.add_argument("--e2e-utts", type=int, default=512, help="utterances in the end-to-end (features.pkl -> prediction.pkl) legs")
     return p.parse_args()
 
 
@@ -77,29 +92,20 @@ def build_model(torch, device, precision):
 
 
 def timed_steps(torch, dist, model, x, steps, warmup, world):
+    """W untimed warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize on both sides.  Inside the
+    timed region only the dominant kernel (timing slot 2) is bracketed by HIP events on the launch stream; the per-kernel
+    breakdown (every launch bracketed) runs directly AFTER the timed region -- the only host work in between is reading
+    back the <= 256 already-completed events of slot 2 -- so both are taken in the same warmed-up clock state."""
     from dfa_amd import _lib
     ctx = _lib.Context.get(x.device)
-    # per-kernel breakdown from an untimed pass (every launch bracketed by events) BEFORE the warm-up steps, so that the
-    # warm-up runs right up to the barrier of the timed region; inside the timed region only the dominant kernel (slot 2)
-    # is bracketed
-    for _ in range(10):                     # clock ramp / first-touch launches stay out of the per-kernel averages
-        model(x)
-    torch.cuda.synchronize()
-    ctx.timing_reset()
-    ctx.timing(True)
-    for _ in range(20):
-        model(x)
     ctx.timing(False)
-    torch.cuda.synchronize()
-    breakdown = [ctx.timing_read(s) for s in range(4)]
-    ctx.timing_reset()
-    ctx.timing(1 << 2)
     for _ in range(warmup):
         model(x)
+    ctx.timing_reset()
+    ctx.timing(1 << 2)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.timing_reset()                      # the roofline's launch durations cover the timed steps only
     t0 = time.perf_counter()
     for _ in range(steps):
         out = model(x)
@@ -107,9 +113,16 @@ def timed_steps(torch, dist, model, x, steps, warmup, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dominant = ctx.timing_read(2)
+    ctx.timing_reset()
+    ctx.timing(True)
+    for _ in range(30):
+        model(x)
     ctx.timing(False)
-    slots = list(breakdown)
-    slots[2] = ctx.timing_read(2)
+    torch.cuda.synchronize()
+    slots = [ctx.timing_read(s) for s in range(4)]
+    ctx.timing_reset()
+    slots[2] = dominant
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,6 +173,78 @@ def cpu_baseline(torch, sd_cpu, seconds):
                       "one batch of 8"}
 
 
+def write_synthetic_pickle(torch, n, tmp):
+    """features.pkl in the reference schema (README.md:45-103): DataFrame{uttid, features: FloatTensor [180, 321]}."""
+    import pandas as pd
+    g = torch.Generator().manual_seed(4321)
+    feats = torch.randn(n, F, T, generator=g) * 3.2 - 0.07
+    path = os.path.join(tmp, "features.pkl")
+    pd.DataFrame({"uttid": [f"utt_{i:06d}" for i in range(n)], "features": [feats[i].clone() for i in range(n)]}).to_pickle(path)
+    return path
+
+
+def cpu_end_to_end(torch, sd_cpu, features_path, n):
+    """src/predict.py end to end on the host (oracle/predict_ref.py): unpickle -> DataLoader(32, workers 2) -> CPU model ->
+    sigmoid -> prediction.pkl."""
+    from oracle import predict_ref as P
+    torch.set_num_threads(host_cores())
+    out = features_path.replace("features.pkl", "prediction_cpu.pkl")
+    t0 = time.perf_counter()
+    P.predict_end_to_end(features_path, sd_cpu, out, batch_size=32, num_workers=2)
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 2), "unit": "utterances/s", "seconds": round(el, 2),
+            "sample": f"{n} utterances: features.pkl -> DataLoader(batch 32, num_workers 2) -> oracle/torch_ref.py -> "
+                      "prediction.pkl, load and write included (src/predict.py:88-122)"}, out
+
+
+def gpu_end_to_end(torch, device, model_state, features_path, n, cpu_pred_path):
+    """The same file through the product: dfa_amd.predict (unpickle, stack, H2D over PCIe, kernels, D2H, pickle) and the
+    flat-file ingest path of SURVEY 8(f)1 (one-time convert, then memmap -> pinned double-buffered H2D -> kernels)."""
+    import numpy as np
+    import pandas as pd
+    from dfa_amd import ingest, predict
+    tmp = os.path.dirname(features_path)
+    ck = os.path.join(tmp, "cnn2d.pt")
+    torch.save({"model_state": model_state}, ck)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        out = os.path.join(tmp, f"prediction_{prec}.pkl")
+        argv = ["--features", features_path, "--checkpoint", ck, "--model", "cnn2d", "--out", out, "--batch-size", "256",
+                "--precision", prec]
+        predict.main(argv)                                   # first call pays workspace allocation / weight packing
+        t0 = time.perf_counter()
+        predict.main(argv)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        res[f"predict_pkl_{prec}"] = {"value": round(n / el, 1), "unit": "utterances/s", "seconds": round(el, 3)}
+        if prec == "fp32" and cpu_pred_path and os.path.exists(cpu_pred_path):
+            a, b = pd.read_pickle(out), pd.read_pickle(cpu_pred_path)
+            res["max_abs_score_diff_vs_cpu"] = float(np.abs(a["predictions"].values - b["predictions"].values).max())
+    # flat ingest: convert once (timed separately), then stream
+    t0 = time.perf_counter()
+    ingest.convert(features_path, os.path.join(tmp, "flat16"), None, dtype="bf16")
+    res["ingest_convert_seconds"] = round(time.perf_counter() - t0, 3)
+    ff = ingest.FlatFeatures(os.path.join(tmp, "flat16"))
+    model = build_model(torch, device, "bf16")
+    model.load_state_dict(model_state)
+    flat = ff.tensor()
+    predict.predict_scores(model, flat, batch_size=256, apply_sigmoid=True).cpu()
+    t0 = time.perf_counter()
+    reps = 4
+    for _ in range(reps):
+        scores = predict.predict_scores(model, flat, batch_size=256, apply_sigmoid=True).cpu()
+    el = (time.perf_counter() - t0) / reps
+    res["flat_ingest_bf16"] = {"value": round(n / el, 1), "unit": "utterances/s", "seconds": round(el, 4),
+                               "what": "memory-mapped [N,180,321] bf16 file -> FlatBatcher (async double-buffered H2D, "
+                                       "PCIe included) -> kernels -> scores on the host",
+                               "host_bytes_per_utt": F * T * 2}
+    res["sample"] = f"{n} utterances, host-resident; PCIe-inclusive (never the headline value)"
+    return res
+
+
+TRAIN_FLOPS_PER_UTT = 9_621_849_600      # SURVEY.md section 8(d): fwd 3.218 G + wgrad 3.218 G + dgrad(conv2,3) + linear 3.185 G
+
+
 def train_step_metric(torch, device, B, steps=20, warmup=5):
     """Secondary metric (BASELINE configs[2]): CNN2D training step (fwd + bwd + fused AdamW, dropout 0.2, label
     smoothing 0.05) in the bf16-storage mode, utterances/s on this rank."""
@@ -179,8 +264,13 @@ def train_step_metric(torch, device, B, steps=20, warmup=5):
         loss = tr.step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ach = B * TRAIN_FLOPS_PER_UTT / dt / 1e12
     return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
             "batch_per_gpu": B, "loss": round(float(loss.item()), 4),
+            "roofline": {"bound": "mfma", "scope": "whole step (forward + backward + AdamW), algorithmic FLOPs / wall time",
+                         "achieved": round(ach, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_TFLOPS["bf16"], 4), "flops_per_utt": TRAIN_FLOPS_PER_UTT,
+                         "traffic": None},
             "what": "fwd + bwd + fused AdamW, dropout 0.2, label smoothing 0.05 (src/train.py:71-76), 1 GPU"}
 
 
@@ -215,8 +305,25 @@ def other_models_metric(torch, device, B, steps=20, warmup=5):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` by itself: start the N ranks as a CHILD torch.distributed.run (one process per GPU,
+    RCCL) before this process has made any GPU call, relay its output and exit with its code.  Never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -294,7 +401,13 @@ def main():
             line["train_step"] = train_step_metric(torch, device, B)
             line["other_models"] = other_models_metric(torch, device, B)
         if world == 1 and not args.no_cpu_baseline:
+            import tempfile
             line["cpu_baseline"] = cpu_baseline(torch, sd_cpu, args.cpu_seconds)
+            with tempfile.TemporaryDirectory() as tmp:
+                n_e2e = args.e2e_utts
+                fpath = write_synthetic_pickle(torch, n_e2e, tmp)
+                line["cpu_baseline"]["end_to_end"], cpu_pred = cpu_end_to_end(torch, sd_cpu, fpath, n_e2e)
+                line["end_to_end"] = gpu_end_to_end(torch, device, sd_cpu, fpath, n_e2e, cpu_pred)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
