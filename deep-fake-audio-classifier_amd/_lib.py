@@ -15,9 +15,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdfa_hip.so")
 DFA_OK = 0
 E_BAD_SHAPE, E_BAD_DTYPE, E_NULL_PTR, E_NOT_PREPARED, E_HIP, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 DTYPE_F32, DTYPE_BF16 = 0, 1
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 MODEL_CNN2D, MODEL_CNN1D, MODEL_CAE = 0, 1, 2
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,
+              "bf16x3": PREC_BF16X3}
 
 _lib = None
 _lock = threading.Lock()

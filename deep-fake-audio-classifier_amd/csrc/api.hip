@@ -19,7 +19,7 @@ struct Cnn2dPlan {
 
 Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
   Cnn2dPlan p;
-  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
+  const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;   // fp32, or a hi + lo bf16 pair (DFA_PREC_BF16X3)
   p.H1 = T / 2;
   p.H2 = p.H1 / 2;
   size_t off = 0;
@@ -187,7 +187,8 @@ int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count) {
 }
 
 const char* dfa_dominant_kernel(int model, int precision) {
-  if (model == DFA_MODEL_CNN2D) return precision == DFA_PREC_BF16 ? "conv3_m16_meant_kernel" : "conv3x3_mfma_kernel";
+  if (model == DFA_MODEL_CNN2D)
+    return precision == DFA_PREC_BF16 ? "conv3_m16_meant_kernel" : precision == DFA_PREC_BF16X3 ? "conv_split_kernel" : "conv3x3_mfma_kernel";
   return "";
 }
 
@@ -210,7 +211,8 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn2dState& m = ctx->cnn2d;
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_set_params has not been called");
-  if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
+  if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16 && precision != DFA_PREC_BF16X3)
+    return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
   DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // one allocation: w1[288] b1[32] | bias2[64] bias3[128] | wpack2 | wpack3   (sized for fp32, the larger mode)
   const size_t w2_bytes = (size_t)64 * 32 * 9 * 4, w3_bytes = (size_t)128 * 64 * 9 * 4;
@@ -235,6 +237,13 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
   const float* const* p = m.p;
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], p[4], p[5], m.w1, m.b1, 32, ctx->stream));
   DFA_HIP_CHECK(ctx, launch_pack_conv1_mfma(m.w1, m.b1, m.c1pack, m.c1bias, ctx->stream));
+  if (precision == DFA_PREC_BF16X3) {
+    // hi/lo split images (conv_split.hip): the same byte counts as the fp32 images, so they live in the same regions
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3_split(p[6], p[7], p[8], p[9], p[10], p[11], 32, 64, m.c2.wpack, m.c2.bias, 0.5f, ctx->stream));
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3_split(p[12], p[13], p[14], p[15], p[16], p[17], 64, 128, m.c3.wpack, m.c3.bias, 1.0f, ctx->stream));
+    m.prepared_prec = precision;
+    return DFA_OK;
+  }
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], p[8], p[9], p[10], p[11], 32, 0, 32, 64, precision, m.c2.wpack, m.c2.bias, ctx->stream, 1, 0.5f));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], p[14], p[15], p[16], p[17], 64, 0, 64, 128, precision, m.c3.wpack, m.c3.bias, ctx->stream));
   if (precision == DFA_PREC_BF16)
@@ -289,14 +298,17 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ConvArgs a{};
     a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;
     a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
+    if (prec == DFA_PREC_BF16X3) DFA_HIP_CHECK(ctx, launch_cnn2d_block2_split(a, s, ctx->lds_pipe));
+    else DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
   }
   {
     ScopedSlot ts(ctx, 2);
     ConvArgs a{};
     a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
-    if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
+    if (prec == DFA_PREC_BF16X3) {
+      DFA_HIP_CHECK(ctx, launch_cnn2d_block3_split(a, s, ctx->lds_pipe));
+    } else if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
       a.wpack = m.c3_m16;
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3_m16(a, s, ctx->lds_pipe));
     } else {

@@ -28,6 +28,9 @@ __device__ __forceinline__ float load_x<bf16_t>(const bf16_t* p) { return bf16_t
 // instruction writes 16 pixels x 64 bytes = 1 KiB of contiguous channels-last output.  The thread keeps its 8 x 9
 // folded weights in registers (as 4 channel pairs x 9 taps) and walks 4 pixels of the 16 x 16 tile; every tap of every
 // pre-pool row is one packed v_pk_fma_f32 on a channel pair.
+// TO = split_t: the output pixel is [hi: 32 bf16][lo: 32 bf16] with v = hi + lo to 2^-17 (conv_split.hip consumes it)
+struct split_t { unsigned short v; };
+
 template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __restrict__ x, int64_t sb, int64_t st,
                                                                    int64_t sf, const float* __restrict__ w1,
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
     if (more) load_tile((tile + gridDim.y) * C1_TI, xr);
     // the 4 passes keep their outputs in registers; the stores are issued after the prefetched x tile has been written to
     // LDS, so that wait never has this iteration's stores in front of it (vmcnt counts loads and stores in order)
-    constexpr int NVS = (int)(8 * sizeof(TO) / 16);
+    constexpr bool SPLIT = std::is_same<TO, split_t>::value;
+    constexpr int NVS = SPLIT ? 2 : (int)(8 * sizeof(TO) / 16);
     uint4 outv[C1_TI / 4][NVS];
 #pragma unroll
     for (int pass = 0; pass < C1_TI / 4; ++pass) {
@@ -122,20 +126,35 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
 #pragma unroll
         for (int c = 0; c < 8; ++c) o[c] *= ds[c];
       }
-      TO ov[8];
+      if constexpr (SPLIT) {
+        float h[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ov[c] = cvt_out<TO>(o[c]);
+        for (int c = 0; c < 8; ++c) h[c] = bf16_to_float(float_to_bf16(o[c]));
+        outv[pass][0] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        outv[pass][1] = make_uint4(pack_bf16x2(o[0] - h[0], o[1] - h[1]), pack_bf16x2(o[2] - h[2], o[3] - h[3]),
+                                   pack_bf16x2(o[4] - h[4], o[5] - h[5]), pack_bf16x2(o[6] - h[6], o[7] - h[7]));
+      } else {
+        TO ov[8];
 #pragma unroll
-      for (int v = 0; v < NVS; ++v) outv[pass][v] = reinterpret_cast<const uint4*>(ov)[v];
+        for (int c = 0; c < 8; ++c) ov[c] = cvt_out<TO>(o[c]);
+#pragma unroll
+        for (int v = 0; v < NVS; ++v) outv[pass][v] = reinterpret_cast<const uint4*>(ov)[v];
+      }
     }
     if (more) store_tile(buf ^ 1, (tile + gridDim.y) * C1_TI, xr);
 #pragma unroll
     for (int pass = 0; pass < C1_TI / 4; ++pass) {
       const int i = i0 + pass * 4 + rq;
       if (i < Ho && f < F) {
-        TO* op = out + (((uint64_t)b * Ho + i) * F + f) * 32 + q * 8;
+        if constexpr (SPLIT) {
+          unsigned short* op = (unsigned short*)out + (((uint64_t)b * Ho + i) * F + f) * 64 + q * 8;
+          *reinterpret_cast<uint4*>(op) = outv[pass][0];          // hi plane: channels 8q .. 8q+7
+          *reinterpret_cast<uint4*>(op + 32) = outv[pass][1];     // lo plane
+        } else {
+          TO* op = out + (((uint64_t)b * Ho + i) * F + f) * 32 + q * 8;
 #pragma unroll
-        for (int v = 0; v < NVS; ++v) reinterpret_cast<uint4*>(op)[v] = outv[pass][v];
+          for (int v = 0; v < NVS; ++v) reinterpret_cast<uint4*>(op)[v] = outv[pass][v];
+        }
       }
     }
     __syncthreads();
@@ -154,6 +173,15 @@ hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int6
   int ny = (4096 + B * ncols - 1) / (B * ncols);
   ny = ny < 1 ? 1 : (ny > ntiles ? ntiles : ny);
   dim3 grid(ncols, ny, B), block(256);
+  if (out_prec == DFA_PREC_BF16X3) {
+    if (x_dtype == DFA_DTYPE_F32)
+      hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, split_t>), grid, block, 0, s, (const float*)x, sb, st, sf, w1,
+                         b1, (split_t*)out, T, F, Ho, dc);
+    else
+      hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<bf16_t, split_t>), grid, block, 0, s, (const bf16_t*)x, sb, st, sf,
+                         w1, b1, (split_t*)out, T, F, Ho, dc);
+    return hipGetLastError();
+  }
   if (x_dtype == DFA_DTYPE_F32 && out_prec == DFA_PREC_F32)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, float>), grid, block, 0, s, (const float*)x, sb, st, sf, w1,
                        b1, (float*)out, T, F, Ho, dc);

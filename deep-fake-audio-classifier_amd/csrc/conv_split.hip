@@ -1,0 +1,317 @@
+// conv_split.hip -- the parity-grade fast mode (DFA_PREC_BF16X3): CNN2D blocks 2 and 3 (src/model.py:21-29,37) with every
+// fp32 value carried as a PAIR of bf16 numbers, v = hi + lo (hi = bf16(v), lo = bf16(v - hi): 16 significant bits), and
+// every product taken as three bf16 MFMAs accumulated in fp32:
+//     w * x  ~=  w_hi*x_hi + w_lo*x_hi + w_hi*x_lo            (the dropped w_lo*x_lo term is 2^-18 of the product)
+// Products of bf16 numbers are exact in the fp32 accumulator, so the result differs from the exact-fp32 path
+// (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate) only by the 2^-17 representation error of the operands: logits stay
+// within 1e-4 of the reference (golden tests) at 3/16 of the fp32-MFMA cost.
+//
+// Layout.  A split activation pixel is [hi: C bf16][lo: C bf16] (4C bytes, the size of the fp32 pixel), channels-last as
+// everywhere else; conv1.hip writes a1 in this form, the block-2 epilogue writes a2 in this form.  In LDS a pixel slot keeps
+// that layout; its 16-byte chunk c sits at physical chunk c ^ swz(slot) with swz = slot & 6 (128-byte pixels, the
+// conv3_m16.hip swizzle) or (slot & 7) << 1 (256-byte pixels): conflict-free for the gfx950 ds_read_b128 lane groups over
+// all tap columns, pixel tiles, k-steps and hi/lo halves (exhaustive check: tests/test_host_api.py).
+//
+// Tiling (v_mfma_f32_16x16x32_bf16, as conv3_m16.hip): workgroup = (utterance, 32-column strip, ALL output channels)
+// walking down T over a 3-block LDS ring of input rows (LDS-DMA staging, each input element leaves HBM once); wave = 16
+// output channels x 32 pixels x 2 rows (16 accumulator registers).  The wave's hi and lo weight fragments for all 9 taps
+// stay in registers (72 VGPRs for 32 input channels, 144 for 64).  An x_hi fragment read (ds_read_b128: 8 channels of 16
+// pixels) feeds 4 MFMAs (w_hi and w_lo, for the two output rows sharing the input row), an x_lo fragment 2.
+#include "dfa_internal.h"
+
+namespace dfa {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int CIN>
+struct SplitCfg {
+  static constexpr int PB = CIN * 4;             // bytes per split pixel
+  static constexpr int CPP = PB / 16;            // 16-byte chunks per pixel (8 or 16); lo half starts at chunk CPP/2
+  static constexpr int KK = CIN / 32;            // k-steps of 32 input channels
+  static constexpr int SP = 36, ROWB = SP * PB, BR = 2;
+  static constexpr int RING_BYTES = 3 * BR * ROWB;
+  static __device__ __forceinline__ int swz(int slot) { return CPP == 8 ? (slot & 6) : ((slot & 7) << 1); }
+};
+
+enum { SPLIT_EPI_POOL_H2 = 0, SPLIT_EPI_MEAN_T = 1 };
+
+static __device__ __forceinline__ f32x4_t mma16s(const uint4& w, const uint4& x, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
+}
+
+// NW waves = NW*16 output channels = COUT.  PIPE = false: the compiler-scheduled twin (bit-identical output).
+template <int CIN, int NW, int EPI, bool PIPE>
+__global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
+  using C = SplitCfg<CIN>;
+  constexpr int PB = C::PB, CPP = C::CPP, KK = C::KK, SP = C::SP, ROWB = C::ROWB, BR = C::BR, NT = 64 * NW;
+  constexpr int COUT = 16 * NW;
+  constexpr int NCH = BR * SP * CPP, NLD = (NCH + NT - 1) / NT;
+  constexpr int PF = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, q = lane >> 4;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, xi = bid >> 3;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+  const int b = logical / a.nstrips, strip = logical - b * a.nstrips;
+  const int f0 = strip * 32;
+  const int H = a.H, W = a.W;
+  const char* in_b = (const char*)a.in + (size_t)b * H * W * PB;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const float rlim = relu_limit();
+
+  // ---- weights [tap][kk][hi|lo]: 18*KK fragments for the kernel's lifetime
+  uint4 w[9][KK][2];
+  {
+    const uint4* wp = a.wpack + (size_t)wave * 9 * KK * 2 * 64 + lane;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) w[tap][kk][hl] = wp[((tap * KK + kk) * 2 + hl) * 64];
+  }
+  float* bias_lds = (float*)(smem + C::RING_BYTES);
+  if (tid < COUT) bias_lds[tid] = a.bias[tid];
+
+  // per-lane fragment offsets inside a ring row: slot = p + dx (second pixel tile: +16 slots, swizzle unchanged);
+  // logical chunk = hl*(CPP/2) + 4*kk + q  ->  (hl, kk) is one XOR with a multiple of 64 bytes
+  int xa[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int slot = p + dx;
+    xa[dx] = slot * PB + ((q ^ C::swz(slot)) << 4);
+  }
+
+  // ---- LDS-DMA staging of a ring block: the thread's k-th PHYSICAL chunk; the swizzle lives in the source address
+  int s_off[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int g = k * NT + tid;
+    const int rowi = g / (SP * CPP), rem = g - rowi * (SP * CPP);
+    const int slot = rem / CPP, cph = rem % CPP;
+    const int c = cph ^ C::swz(slot);
+    const int f = f0 - 1 + slot;
+    const bool ok = (g < NCH) && (slot < 34) && (f >= 0) && (f < W);
+    s_off[k] = ok ? (rowi * W + f) * PB + c * 16 : -1;
+  }
+  auto stage_dma = [&](int j, int ringblk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int g = k * NT + tid;
+      if (g < NCH) {
+        const int t = BR * j - 1 + g / (SP * CPP);
+        const char* src = (s_off[k] >= 0 && t >= 0 && t < H) ? in_b + (ptrdiff_t)(BR * j - 1) * W * PB + s_off[k]
+                                                             : (const char*)a.zero_page;
+        char* dst = smem + ringblk * BR * ROWB + (k * NT + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4_t cs[2];        // MEAN_T: running column sums per pixel tile
+  cs[0] = cs[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int niter = (H + BR - 1) / BR;
+  stage_dma(0, 0);
+  stage_dma(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto unit = [&](auto ph_c, int it) {
+    constexpr int PH = decltype(ph_c)::value;
+    const int t0 = BR * it;
+    f32x4_t acc0[2], acc1[2];
+    constexpr int PER_ROW = 3 * KK * 4;            // fragment reads per input row, in (dx, kk, hi|lo, pixel tile) order
+    constexpr int NR = 4 * PER_ROW;
+    constexpr int C_RELU0 = 3 * PER_ROW + 2;       // acc0's last MFMAs belong to consume step 3*PER_ROW - 1
+    u32x4_t xbuf[PF];
+    auto step = [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      if constexpr (s < NR) {
+        constexpr int i = s / PER_ROW, dx = (s / (KK * 4)) % 3, kk = (s / 4) % KK, hl = (s / 2) % 2, pb = s % 2;
+        constexpr int ringrow = (BR * PH + i) % (3 * BR);
+        constexpr int c0 = hl * (CPP / 2) + 4 * kk;
+        xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, PIPE>(lds0 + (xa[dx] ^ (c0 << 4)));
+      }
+      if constexpr (s >= PF - 1) {
+        constexpr int c = s - (PF - 1);
+        constexpr int i = c / PER_ROW, dx = (c / (KK * 4)) % 3, kk = (c / 4) % KK, hl = (c / 2) % 2, pb = c % 2;
+        constexpr int young = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
+        if constexpr (PIPE) lds_wait<young>(xbuf[c % PF]);
+        const uint4 xv = __builtin_bit_cast(uint4, xbuf[c % PF]);
+        if constexpr (i <= 2) {
+          acc0[pb] = mma16s(w[i * 3 + dx][kk][0], xv, acc0[pb]);                        // w_hi * (x_hi | x_lo)
+          if constexpr (hl == 0) acc0[pb] = mma16s(w[i * 3 + dx][kk][1], xv, acc0[pb]); // w_lo * x_hi
+        }
+        if constexpr (i >= 1) {
+          acc1[pb] = mma16s(w[(i - 1) * 3 + dx][kk][0], xv, acc1[pb]);
+          if constexpr (hl == 0) acc1[pb] = mma16s(w[(i - 1) * 3 + dx][kk][1], xv, acc1[pb]);
+        }
+        if constexpr (c == C_RELU0) {   // rows 0..2 done for acc0: its ReLU hides under acc1's last MFMAs
+#pragma unroll
+          for (int pb2 = 0; pb2 < 2; ++pb2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0[pb2][e] = relu1(acc0[pb2][e], rlim);
+        }
+      }
+    };
+    {   // bias = accumulator init: channels 16*wave + 4*q + e
+      const unsigned ba = lds0 + C::RING_BYTES + (wave * 16 + 4 * q) * 4;
+      u32x4_t b0 = lds_frag<0, PIPE>(ba);
+      static_for(std::make_integer_sequence<int, PF - 1>{}, step);
+      if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b0) : "n"(PF - 1));
+      acc0[0] = acc0[1] = acc1[0] = acc1[1] = __builtin_bit_cast(f32x4_t, b0);
+    }
+    static_for(std::make_integer_sequence<int, NR>{}, [&](auto s_c) {
+      step(std::integral_constant<int, decltype(s_c)::value + PF - 1>{});
+    });
+    if constexpr (EPI == SPLIT_EPI_MEAN_T) {
+      if (t0 + 1 < H) {   // wave-uniform
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[pb][e] += acc0[pb][e] + relu1(acc1[pb][e], rlim);
+      } else if (t0 < H) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[pb][e] += acc0[pb][e];
+      }
+    } else {
+      // AvgPool2d((2,1)) over the row pair (the 1/2 is in the weights), split into hi + lo and stored as two bf16 planes of
+      // the output pixel.  permlane16_swap hands every lane 8 consecutive channels of ONE pixel tile, so hi and lo leave
+      // as one 16-byte store each: rows (q) 0/2 keep pixel tile 0 (channels 8*(q/2) .. +7), rows 1/3 take pixel tile 1.
+      const int Ho = H >> 1, to = t0 >> 1;
+      unsigned hi[2][2], lo[2][2];   // [pixel tile][dword]
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        float v[4], h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc0[pb][e] + relu1(acc1[pb][e], rlim);
+          h[e] = bf16_to_float(float_to_bf16(v[e]));
+        }
+        hi[pb][0] = pack_bf16x2(v[0], v[1]); hi[pb][1] = pack_bf16x2(v[2], v[3]);
+        lo[pb][0] = pack_bf16x2(v[0] - h[0], v[1] - h[1]); lo[pb][1] = pack_bf16x2(v[2] - h[2], v[3] - h[3]);
+      }
+      const auto h0 = __builtin_amdgcn_permlane16_swap(hi[0][0], hi[1][0], false, false);
+      const auto h1 = __builtin_amdgcn_permlane16_swap(hi[0][1], hi[1][1], false, false);
+      const auto l0 = __builtin_amdgcn_permlane16_swap(lo[0][0], lo[1][0], false, false);
+      const auto l1 = __builtin_amdgcn_permlane16_swap(lo[0][1], lo[1][1], false, false);
+      // after the swap: element [0] = channels 4*(q&~1).. of this lane's tile, element [1] = the next 4 channels
+      const int tile = q & 1, cb = 16 * wave + 8 * (q >> 1);
+      const int col = f0 + 16 * tile + p;
+      if (to < Ho && col < W) {
+        bf16_t* o = (bf16_t*)a.out + (((size_t)b * Ho + to) * W + col) * (2 * COUT) + cb;
+        *(uint4*)o = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+        *(uint4*)(o + COUT) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+      }
+    }
+  };
+
+  auto iteration = [&](auto ph_c, int it) {
+    constexpr int PH = decltype(ph_c)::value;
+    if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
+    unit(ph_c, it);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int it = 0; it < niter; it += 3) {
+    iteration(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
+    if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
+  }
+
+  if constexpr (EPI == SPLIT_EPI_MEAN_T) {
+    // embedding rows [b][channel][col]: 16 consecutive columns per (channel, quarter-wave)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int col = f0 + 16 * pb + p;
+      if (col < W) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 16 * wave + 4 * q + e;
+          a.emb[((size_t)b * COUT + c) * W + col] = cs[pb][e] * a.inv_h;
+        }
+      }
+    }
+  }
+}
+
+// w[COUT][CIN][3][3] (+ folded eval BatchNorm, * post_scale) -> wsplit[COUT/16][9 taps][CIN/32][hi|lo][64 lanes] x 16 B:
+// lane (c = lane&15, q = lane>>4), element j: v = s[co] * w[co = 16*tile + c][ci = 32*kk + 8*q + j][tap] * post_scale;
+// hi = bf16(v), lo = bf16(v - hi).  bias[co] = folded bias * post_scale (fp32).
+__global__ void fold_pack_conv3x3_split_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                               const float* __restrict__ g, const float* __restrict__ beta,
+                                               const float* __restrict__ mean, const float* __restrict__ var, int cin,
+                                               int cout, uint4* __restrict__ wpack, float* __restrict__ bias,
+                                               float post_scale) {
+  const int kkn = cin / 32;
+  const int total = (cout / 16) * 9 * kkn * 2 * 64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout) {
+    const float s = g[i] / sqrtf(var[i] + kBnEps);
+    bias[i] = ((b[i] - mean[i]) * s + beta[i]) * post_scale;
+  }
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int hl = rest & 1; rest >>= 1;
+  const int kk = rest % kkn; rest /= kkn;
+  const int tap = rest % 9;
+  const int tile = rest / 9;
+  const int co = tile * 16 + (lane & 15), q = lane >> 4;
+  const float s = g[co] / sqrtf(var[co] + kBnEps);
+  bf16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float wv = w[((size_t)co * cin + 32 * kk + 8 * q + j) * 9 + tap] * s * post_scale;
+    const bf16_t h = float_to_bf16(wv);
+    v[j] = hl ? float_to_bf16(wv - bf16_to_float(h)) : h;
+  }
+  wpack[i] = *reinterpret_cast<const uint4*>(v);
+}
+
+hipError_t launch_fold_pack_conv3x3_split(const float* w, const float* b, const float* g, const float* beta,
+                                          const float* mean, const float* var, int cin, int cout, uint4* wpack,
+                                          float* bias, float post_scale, hipStream_t s) {
+  int total = (cout / 16) * 9 * (cin / 32) * 2 * 64;
+  if (total < cout) total = cout;
+  hipLaunchKernelGGL(fold_pack_conv3x3_split_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, b, g, beta, mean, var,
+                     cin, cout, wpack, bias, post_scale);
+  return hipGetLastError();
+}
+
+template <int CIN, int NW, int EPI, bool PIPE>
+static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
+  auto kern = conv_split_kernel<CIN, NW, EPI, PIPE>;
+  constexpr int LDS = SplitCfg<CIN>::RING_BYTES + NW * 16 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, 1, 1), dim3(64 * NW), LDS, stream, a);
+  return hipGetLastError();
+}
+
+// block 2: a.in = a1 split [B][H][W][2*32], a.out = a2 split [B][H/2][W][2*64]
+hipError_t launch_cnn2d_block2_split(const ConvArgs& a0, hipStream_t stream, int pipe) {
+  ConvArgs a = a0;
+  a.nstrips = (a.W + 31) / 32;
+  return pipe ? launch_split_t<32, 4, SPLIT_EPI_POOL_H2, true>(a, stream) : launch_split_t<32, 4, SPLIT_EPI_POOL_H2, false>(a, stream);
+}
+
+// block 3: a.in = a2 split [B][H][W][2*64], a.emb = [B][128][W] fp32 (mean over H)
+hipError_t launch_cnn2d_block3_split(const ConvArgs& a0, hipStream_t stream, int pipe) {
+  ConvArgs a = a0;
+  a.nstrips = (a.W + 31) / 32;
+  return pipe ? launch_split_t<64, 8, SPLIT_EPI_MEAN_T, true>(a, stream) : launch_split_t<64, 8, SPLIT_EPI_MEAN_T, false>(a, stream);
+}
+
+}  // namespace dfa

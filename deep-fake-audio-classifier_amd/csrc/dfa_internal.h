@@ -248,6 +248,12 @@ hipError_t launch_wgrad3x3(int prec, int cin, int cout, const void* dz, const vo
 hipError_t launch_fold_pack_conv3x3_m16(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                                         const float* var, int cin, int cout, uint4* wpack, hipStream_t s, int fold = 1);
 hipError_t launch_train_fwd3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
+// conv_split.hip (DFA_PREC_BF16X3)
+hipError_t launch_fold_pack_conv3x3_split(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                                          const float* var, int cin, int cout, uint4* wpack, float* bias, float post_scale,
+                                          hipStream_t s);
+hipError_t launch_cnn2d_block2_split(const ConvArgs& a, hipStream_t s, int pipe = 1);
+hipError_t launch_cnn2d_block3_split(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_cnn2d_block3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
                                       int ci_off, int co_off, float* dw, float* db, hipStream_t s);

@@ -168,7 +168,7 @@ def _main():
     p.add_argument("--in-features", type=int, default=180)
     p.add_argument("--dropout", type=float, default=0.2)
     p.add_argument("--apply-sigmoid", action="store_true")
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"])
     sw = p.add_mutually_exclusive_group()
     sw.add_argument("--swap-tf", dest="swap_tf", action="store_true")
     sw.add_argument("--no-swap-tf", dest="swap_tf", action="store_false")

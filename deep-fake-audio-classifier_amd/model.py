@@ -21,8 +21,10 @@ from ._params import BatchNormParams, ConvParams, LinearParams, Slots, tensors_s
 class CNN2D(nn.Module):
     """2-D CNN over the time x feature grid (reference: src/model.py:5-42).
 
-    precision: "fp32" (default; exact-fp32 MFMA, logits within 1e-4 of the reference) or "bf16" (bf16 storage,
-    fp32 accumulate: the throughput mode of BASELINE.json configs[1]).  Env DFA_PRECISION overrides the default.
+    precision: "fp32" (default; exact-fp32 MFMA, logits within 1e-4 of the reference), "bf16" (bf16 storage, fp32
+    accumulate: the throughput mode of BASELINE.json configs[1]) or "bf16x3" (eval only: hi + lo bf16 operands, three bf16
+    MFMAs per product -- logits within 1e-4 of the reference at several times the fp32 rate).  Env DFA_PRECISION overrides
+    the default.
     """
 
     # reference nn.Sequential indices that own parameters (src/model.py:13-29)

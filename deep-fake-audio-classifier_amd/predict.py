@@ -127,7 +127,7 @@ def parse_args(argv=None):
     p.add_argument("--dropout", type=float, default=0.3)
     p.add_argument("--apply-sigmoid", action="store_true", default=True)
     p.add_argument("--no-apply-sigmoid", action="store_true", default=False)
-    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"])
     sw = p.add_mutually_exclusive_group()
     sw.add_argument("--swap-tf", dest="swap_tf", action="store_true", help="swap time and feature dims (default)")
     sw.add_argument("--no-swap-tf", dest="swap_tf", action="store_false")

@@ -45,9 +45,13 @@ extern "C" {
 
 /* arithmetic mode of the convolution stack (chosen at prepare time)
  *   DFA_PREC_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) -- parity mode, logits within 1e-4
- *   DFA_PREC_BF16 : bf16 storage of weights/activations, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- throughput mode */
+ *   DFA_PREC_BF16 : bf16 storage of weights/activations, fp32 accumulate (v_mfma_f32_32x32x16_bf16) -- throughput mode
+ *   DFA_PREC_BF16X3 : CNN2D only.  Every weight and activation is carried as hi + lo bf16 (16 significant bits) and every
+ *                   product is three bf16 MFMAs (hi*hi + lo*hi + hi*lo) accumulated in fp32 -- parity-grade (logits within
+ *                   1e-4 of the reference like DFA_PREC_F32) at 3/16 of the fp32-MFMA cost */
 #define DFA_PREC_F32 0
 #define DFA_PREC_BF16 1
+#define DFA_PREC_BF16X3 2
 
 /* model ids for dfa_workspace_bytes */
 #define DFA_MODEL_CNN2D 0

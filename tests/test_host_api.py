@@ -208,7 +208,7 @@ def test_pipelined_lds_reads_are_never_touched_in_flight():
     csrc = os.path.join(root, "deep-fake-audio-classifier_amd", "csrc")
     total = 0
     for name in ("conv3x3_inst_cnn2d.hip", "conv3x3_inst_cae.hip", "conv12_fused.hip", "conv3_m16.hip", "wgrad_mfma.hip",
-                 "conv3x3_inst_train.hip"):
+                 "conv3x3_inst_train.hip", "conv_split.hip"):
         kernels, nreads, violations = chk.check_asm(chk.compile_to_asm(os.path.join(csrc, name)))
         assert not violations, violations[:5]
         total += nreads
@@ -234,3 +234,33 @@ def test_m16_swizzle_is_conflict_free():
                         addr = slot * 128 + (((4 * kk + q) ^ (slot & 6)) << 4)
                         quads.add((addr // 16) % 16)
                     assert len(quads) == 16, (dx, pb, kk)
+
+
+def test_split_kernel_swizzles_are_conflict_free():
+    """conv_split.hip keeps split pixels ([hi C bf16][lo C bf16]) in LDS with chunk c at physical chunk c ^ swz(slot):
+    swz = slot & 6 for 128-byte pixels (C = 32), (slot & 7) << 1 for 256-byte pixels (C = 64).  Within each of the four
+    16-lane groups gfx950 services a ds_read_b128 in, the 16 accesses must fall in 16 distinct bank quads ((addr / 16) mod
+    16).  Exhaustive over tap column, pixel tile, k-step, hi/lo half and lane group."""
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+              list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+              list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+    for cin, swz in ((32, lambda s: s & 6), (64, lambda s: (s & 7) << 1)):
+        pb_bytes, cpp, kkn = cin * 4, cin // 4, cin // 32
+        for dx in range(3):
+            for tile in range(2):
+                for kk in range(kkn):
+                    for hl in range(2):
+                        c0 = hl * (cpp // 2) + 4 * kk
+                        for grp in groups:
+                            quads = set()
+                            for lane in grp:
+                                p, q = lane & 15, lane >> 4
+                                slot = 16 * tile + p + dx
+                                # the kernel's address: (slot*PB + ((q ^ swz(p+dx)) << 4)) ^ (c0 << 4), tile = +16*PB
+                                addr = ((p + dx) * pb_bytes + ((q ^ swz(p + dx)) << 4)) ^ (c0 << 4)
+                                addr += 16 * tile * pb_bytes
+                                assert addr // pb_bytes == slot                      # stays inside its pixel slot
+                                assert (addr % pb_bytes) // 16 == (c0 + q) ^ swz(slot)  # = logical chunk ^ swizzle
+                                quads.add((addr // 16) % 16)
+                            assert len(quads) == 16, (cin, dx, tile, kk, hl)

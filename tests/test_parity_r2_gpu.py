@@ -272,3 +272,89 @@ def test_two_models_of_one_class_interleaved(golden):
     wd = O.cnn1d_forward({k: v.cpu().numpy() for k, v in d.state_dict().items()}, np.swapaxes(g1["t64.x_stored"], 1, 2))
     for m, want in ((c, wc), (d, wd), (c, wc)):
         np.testing.assert_allclose(m(x1).cpu().numpy(), want, atol=TOL_F32, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ bf16x3 (split-bf16) mode
+@pytest.mark.parametrize("tag", ["t321", "t64", "t7", "t16"])
+def test_cnn2d_bf16x3_matches_golden_at_fp32_tolerance(golden, tag):
+    """The hi + lo split mode (three bf16 MFMAs per product) must meet the SAME bar as the exact-fp32 mode: the reference's
+    logits within 1e-4, embeddings to fp32-level tolerance, strided and contiguous inputs alike."""
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd, "bf16x3")
+    stored = torch.from_numpy(g[f"{tag}.x_stored"]).to("cuda")
+    x = stored.transpose(1, 2)
+    logits, emb = model(x, return_embedding=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g[f"{tag}.logits"], atol=TOL_F32, rtol=0)
+    if tag != "t16":
+        np.testing.assert_allclose(emb.cpu().numpy(), g[f"{tag}.embedding"], atol=3e-5, rtol=3e-5)
+    assert torch.equal(model(x.contiguous()), logits)
+
+
+@pytest.mark.parametrize("B,T", [(1, 321), (5, 33), (2, 4), (3, 130), (2, 5)])
+def test_cnn2d_bf16x3_matches_oracle_random_shapes(golden, B, T):
+    sd, _ = golden("cnn2d_eval")
+    model = _model_from_sd(sd, "bf16x3")
+    g = torch.Generator().manual_seed(300 + B * 1000 + T)
+    stored = torch.randn(B, 180, T, generator=g) * 3.2 - 0.07
+    want, inter = O.cnn2d_forward(sd, stored.numpy().swapaxes(1, 2), return_intermediates=True)
+    logits, emb = model(stored.to("cuda").transpose(1, 2), return_embedding=True)
+    np.testing.assert_allclose(emb.cpu().numpy(), inter["embedding"], atol=3e-5, rtol=3e-5)
+    np.testing.assert_allclose(logits.cpu().numpy(), want, atol=TOL_F32, rtol=0)
+
+
+def test_cnn2d_bf16x3_ragged_widths_twins_and_batch_independence(golden):
+    """F = 40 / 65 (ragged last strip), the asm-pipelined kernels against their compiler-scheduled twins (bit-identical),
+    and every utterance of a [256,321,180] batch equal to its batch-of-one result."""
+    from dfa_amd import _lib
+    from dfa_amd.model import CNN2D
+    ctx = _lib.Context.get(torch.device("cuda"))
+    for F in (40, 65):
+        torch.manual_seed(F)
+        m = CNN2D(in_features=F, precision="bf16x3").to("cuda").eval()
+        with torch.no_grad():
+            m.classifier.weight.mul_(30.0)
+        sdf = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+        x = torch.randn(2, 21, F)
+        np.testing.assert_allclose(m(x.to("cuda")).cpu().numpy(), O.cnn2d_forward(sdf, x.numpy()), atol=TOL_F32, rtol=0)
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd, "bf16x3")
+    gen = torch.Generator().manual_seed(7)
+    stored = (torch.randn(256, 180, 321, generator=gen) * 3.2 - 0.07).to("cuda")
+    x = stored.transpose(1, 2)
+    try:
+        ctx.set_option("lds_pipe", 0)
+        l0, e0 = model(x, return_embedding=True)
+        ctx.set_option("lds_pipe", 1)
+        l1, e1 = model(x, return_embedding=True)
+    finally:
+        ctx.set_option("lds_pipe", 1)
+    assert torch.equal(l0, l1) and torch.equal(e0, e1)
+    for idx in (0, 100, 255):
+        assert torch.equal(model(x[idx:idx + 1]), l1[idx:idx + 1])
+    want = R.cnn2d_forward(sd, stored[:3].cpu().transpose(1, 2))
+    np.testing.assert_allclose(l1[:3].cpu().numpy(), want.numpy(), atol=TOL_F32, rtol=0)
+    # bf16 features are accepted too (they are exact in the hi plane)
+    xb = stored[:4].to(torch.bfloat16)
+    want_b = R.cnn2d_forward(sd, xb.float().cpu().transpose(1, 2))
+    np.testing.assert_allclose(model(xb.transpose(1, 2)).cpu().numpy(), want_b.numpy(), atol=TOL_F32, rtol=0)
+
+
+def test_eer2000_bf16x3_predictions_and_eer_identical_to_reference(eer_files):
+    """The N=2000 set in the split mode: every score within 1e-4 of the reference's, EER identical (sigmoid and raw)."""
+    from dfa_amd import evaluation, predict
+    z, td, fp, lp, ck, labels = eer_files
+    for tag, flag in (("sigmoid", []), ("logits", ["--no-apply-sigmoid"])):
+        out = str(td / f"prediction_x3_{tag}.pkl")
+        predict.main(["--features", fp, "--checkpoint", ck, "--model", "cnn2d", "--out", out, "--batch-size", "256",
+                      "--precision", "bf16x3"] + flag)
+        got = pd.read_pickle(out)
+        np.testing.assert_allclose(got["predictions"].values, z[f"{tag}.predictions"], atol=TOL_F32, rtol=0)
+        res = evaluation.score_prediction_file(out, lp)
+        assert res["eer"] == float(z[f"{tag}.eer"][0]), (tag, res["eer"])
+
+
+def test_bf16x3_is_eval_only(golden):
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd, "bf16x3").train()
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 16, 180, device="cuda"))
