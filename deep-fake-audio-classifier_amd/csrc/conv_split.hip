@@ -23,27 +23,32 @@ namespace dfa {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-template <int CIN>
+// SPLIT = false: the same kernel on plain bf16 pixels (one MFMA per product) -- the training step's data-gradient
+// convolutions (dz3 -> da2 with 128 input channels in ONE launch, dz2 -> da1), EPI_PLAIN_BF16 epilogue.
+template <int CIN, bool SPLIT = true>
 struct SplitCfg {
-  static constexpr int PB = CIN * 4;             // bytes per split pixel
-  static constexpr int CPP = PB / 16;            // 16-byte chunks per pixel (8 or 16); lo half starts at chunk CPP/2
+  static constexpr int PB = CIN * (SPLIT ? 4 : 2);  // bytes per pixel ([hi CIN bf16][lo CIN bf16] when split)
+  static constexpr int CPP = PB / 16;            // 16-byte chunks per pixel (8 or 16); the lo half starts at chunk CPP/2
   static constexpr int KK = CIN / 32;            // k-steps of 32 input channels
+  static constexpr int HL = SPLIT ? 2 : 1;
+  static_assert(PB == 128 || PB == 256, "swizzles exist for 128- and 256-byte pixels");
   static constexpr int SP = 36, ROWB = SP * PB, BR = 2;
   static constexpr int RING_BYTES = 3 * BR * ROWB;
   static __device__ __forceinline__ int swz(int slot) { return CPP == 8 ? (slot & 6) : ((slot & 7) << 1); }
 };
 
-enum { SPLIT_EPI_POOL_H2 = 0, SPLIT_EPI_MEAN_T = 1 };
+enum { SPLIT_EPI_POOL_H2 = 0, SPLIT_EPI_MEAN_T = 1, SPLIT_EPI_PLAIN_BF16 = 2 };
 
 static __device__ __forceinline__ f32x4_t mma16s(const uint4& w, const uint4& x, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
 }
 
 // NW waves = NW*16 output channels = COUT.  PIPE = false: the compiler-scheduled twin (bit-identical output).
-template <int CIN, int NW, int EPI, bool PIPE>
+template <int CIN, int NW, int EPI, bool PIPE, bool SPLIT = true>
 __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
-  using C = SplitCfg<CIN>;
-  constexpr int PB = C::PB, CPP = C::CPP, KK = C::KK, SP = C::SP, ROWB = C::ROWB, BR = C::BR, NT = 64 * NW;
+  using C = SplitCfg<CIN, SPLIT>;
+  constexpr int PB = C::PB, CPP = C::CPP, KK = C::KK, HL = C::HL, SP = C::SP, ROWB = C::ROWB, BR = C::BR, NT = 64 * NW;
+  static_assert(SPLIT || EPI == SPLIT_EPI_PLAIN_BF16, "the plain-bf16 form is the data-gradient convolution");
   constexpr int COUT = 16 * NW;
   constexpr int NCH = BR * SP * CPP, NLD = (NCH + NT - 1) / NT;
   constexpr int PF = 4;
@@ -63,15 +68,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   const float rlim = relu_limit();
 
   // ---- weights [tap][kk][hi|lo]: 18*KK fragments for the kernel's lifetime
-  uint4 w[9][KK][2];
+  uint4 w[9][KK][HL];
   {
-    const uint4* wp = a.wpack + (size_t)wave * 9 * KK * 2 * 64 + lane;
+    const uint4* wp = a.wpack + (size_t)wave * 9 * KK * HL * 64 + lane;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) w[tap][kk][hl] = wp[((tap * KK + kk) * 2 + hl) * 64];
+        for (int hl = 0; hl < HL; ++hl) w[tap][kk][hl] = wp[((tap * KK + kk) * HL + hl) * 64];
   }
   float* bias_lds = (float*)(smem + C::RING_BYTES);
   if (tid < COUT) bias_lds[tid] = a.bias[tid];
@@ -125,33 +130,33 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     constexpr int PH = decltype(ph_c)::value;
     const int t0 = BR * it;
     f32x4_t acc0[2], acc1[2];
-    constexpr int PER_ROW = 3 * KK * 4;            // fragment reads per input row, in (dx, kk, hi|lo, pixel tile) order
+    constexpr int PER_ROW = 3 * KK * HL * 2;       // fragment reads per input row, in (dx, kk, hi|lo, pixel tile) order
     constexpr int NR = 4 * PER_ROW;
     constexpr int C_RELU0 = 3 * PER_ROW + 2;       // acc0's last MFMAs belong to consume step 3*PER_ROW - 1
     u32x4_t xbuf[PF];
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
       if constexpr (s < NR) {
-        constexpr int i = s / PER_ROW, dx = (s / (KK * 4)) % 3, kk = (s / 4) % KK, hl = (s / 2) % 2, pb = s % 2;
+        constexpr int i = s / PER_ROW, dx = (s / (KK * HL * 2)) % 3, kk = (s / (HL * 2)) % KK, hl = (s / 2) % HL, pb = s % 2;
         constexpr int ringrow = (BR * PH + i) % (3 * BR);
         constexpr int c0 = hl * (CPP / 2) + 4 * kk;
         xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, PIPE>(lds0 + (xa[dx] ^ (c0 << 4)));
       }
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
-        constexpr int i = c / PER_ROW, dx = (c / (KK * 4)) % 3, kk = (c / 4) % KK, hl = (c / 2) % 2, pb = c % 2;
+        constexpr int i = c / PER_ROW, dx = (c / (KK * HL * 2)) % 3, kk = (c / (HL * 2)) % KK, hl = (c / 2) % HL, pb = c % 2;
         constexpr int young = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
         if constexpr (PIPE) lds_wait<young>(xbuf[c % PF]);
         const uint4 xv = __builtin_bit_cast(uint4, xbuf[c % PF]);
         if constexpr (i <= 2) {
           acc0[pb] = mma16s(w[i * 3 + dx][kk][0], xv, acc0[pb]);                        // w_hi * (x_hi | x_lo)
-          if constexpr (hl == 0) acc0[pb] = mma16s(w[i * 3 + dx][kk][1], xv, acc0[pb]); // w_lo * x_hi
+          if constexpr (SPLIT && hl == 0) acc0[pb] = mma16s(w[i * 3 + dx][kk][HL - 1], xv, acc0[pb]); // w_lo * x_hi
         }
         if constexpr (i >= 1) {
           acc1[pb] = mma16s(w[(i - 1) * 3 + dx][kk][0], xv, acc1[pb]);
-          if constexpr (hl == 0) acc1[pb] = mma16s(w[(i - 1) * 3 + dx][kk][1], xv, acc1[pb]);
+          if constexpr (SPLIT && hl == 0) acc1[pb] = mma16s(w[(i - 1) * 3 + dx][kk][HL - 1], xv, acc1[pb]);
         }
-        if constexpr (c == C_RELU0) {   // rows 0..2 done for acc0: its ReLU hides under acc1's last MFMAs
+        if constexpr (c == C_RELU0 && EPI != SPLIT_EPI_PLAIN_BF16) {   // rows 0..2 done for acc0: its ReLU hides under acc1's last MFMAs
 #pragma unroll
           for (int pb2 = 0; pb2 < 2; ++pb2)
 #pragma unroll
@@ -180,6 +185,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
           for (int e = 0; e < 4; ++e) cs[pb][e] += acc0[pb][e];
+      }
+    } else if constexpr (EPI == SPLIT_EPI_PLAIN_BF16) {
+      // no activation: both rows leave as bf16, 8 consecutive channels per lane after permlane16_swap (see below)
+      const int tile = q & 1, cb = 16 * wave + 8 * (q >> 1);
+      const int col = f0 + 16 * tile + p;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const f32x4_t* acc = r ? acc1 : acc0;
+        const auto d0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1]), false, false);
+        const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][2], acc[1][3]), false, false);
+        if (t0 + r < H && col < W)
+          *(uint4*)((bf16_t*)a.out + (((size_t)b * H + t0 + r) * W + col) * COUT + cb) = make_uint4(d0[0], d1[0], d0[1], d1[1]);
       }
     } else {
       // AvgPool2d((2,1)) over the row pair (the 1/2 is in the weights), split into hi + lo and stored as two bf16 planes of
@@ -286,10 +303,10 @@ hipError_t launch_fold_pack_conv3x3_split(const float* w, const float* b, const 
   return hipGetLastError();
 }
 
-template <int CIN, int NW, int EPI, bool PIPE>
+template <int CIN, int NW, int EPI, bool PIPE, bool SPLIT = true>
 static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
-  auto kern = conv_split_kernel<CIN, NW, EPI, PIPE>;
-  constexpr int LDS = SplitCfg<CIN>::RING_BYTES + NW * 16 * 4;
+  auto kern = conv_split_kernel<CIN, NW, EPI, PIPE, SPLIT>;
+  constexpr int LDS = SplitCfg<CIN, SPLIT>::RING_BYTES + NW * 16 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -312,6 +329,51 @@ hipError_t launch_cnn2d_block3_split(const ConvArgs& a0, hipStream_t stream, int
   ConvArgs a = a0;
   a.nstrips = (a.W + 31) / 32;
   return pipe ? launch_split_t<64, 8, SPLIT_EPI_MEAN_T, true>(a, stream) : launch_split_t<64, 8, SPLIT_EPI_MEAN_T, false>(a, stream);
+}
+
+// ---- training: data-gradient convolutions on the same kernel (plain bf16, one launch each)
+// da = conv3x3(dz, W') with W'[ci][co][dy'][dx'] = W[co][ci][2-dy'][2-dx'] (input channels = the forward conv's OUTPUT channels):
+// wpack[cin/16][9 taps][cout/32][64 lanes] x 16 B, lane (c = lane&15, q = lane>>4), element j = w[co = 32*kk + 8*q + j][ci = 16*tile + c][8 - tap]
+__global__ void pack_conv3x3_dgrad_m16_kernel(const float* __restrict__ w, int cin, int cout, uint4* __restrict__ wpack,
+                                              float* __restrict__ bias) {
+  const int kkn = cout / 32;
+  const int total = (cin / 16) * 9 * kkn * 64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cin) bias[i] = 0.f;
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int kk = rest % kkn; rest /= kkn;
+  const int tap = rest % 9;
+  const int tile = rest / 9;
+  const int ci = tile * 16 + (lane & 15), q = lane >> 4;
+  bf16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = float_to_bf16(w[((size_t)(32 * kk + 8 * q + j) * cin + ci) * 9 + (8 - tap)]);
+  wpack[i] = *reinterpret_cast<const uint4*>(v);
+}
+
+hipError_t launch_pack_conv3x3_dgrad_m16(const float* w, int cin, int cout, uint4* wpack, float* bias, hipStream_t s) {
+  int total = (cin / 16) * 9 * (cout / 32) * 64;
+  if (total < cin) total = cin;
+  hipLaunchKernelGGL(pack_conv3x3_dgrad_m16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, cin, cout, wpack, bias);
+  return hipGetLastError();
+}
+
+// block 3 data gradient: a.in = dz3 [B][H][W][128] bf16, a.out = da2 [B][H][W][64] bf16 (one launch: no fp32 partial sums)
+hipError_t launch_train_dgrad3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
+  ConvArgs a = a0;
+  a.nstrips = (a.W + 31) / 32;
+  return pipe ? launch_split_t<128, 4, SPLIT_EPI_PLAIN_BF16, true, false>(a, stream)
+              : launch_split_t<128, 4, SPLIT_EPI_PLAIN_BF16, false, false>(a, stream);
+}
+
+// block 2 data gradient: a.in = dz2 [B][H][W][64] bf16, a.out = da1 [B][H][W][32] bf16
+hipError_t launch_train_dgrad2_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
+  ConvArgs a = a0;
+  a.nstrips = (a.W + 31) / 32;
+  return pipe ? launch_split_t<64, 2, SPLIT_EPI_PLAIN_BF16, true, false>(a, stream)
+              : launch_split_t<64, 2, SPLIT_EPI_PLAIN_BF16, false, false>(a, stream);
 }
 
 }  // namespace dfa

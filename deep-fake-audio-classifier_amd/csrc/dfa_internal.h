@@ -50,6 +50,7 @@ struct Cnn2dState {
   PackedConv t2, t3, d2, d3;              // raw forward images and data-gradient images
   DropCfg train_drop{};
   int train_prec = -1, train_B = 0, train_T = 0;
+  int train_dgrad_m16 = 0;                // the d2/d3 images are in the 16x16x32 order of conv_split.hip (bf16 mode)
 };
 
 struct Cnn1dState {
@@ -91,6 +92,7 @@ struct dfa_ctx {
   int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
   int fuse_conv1 = 1;          // bf16 mode: blocks 1 and 2 in one kernel (conv12_fused.hip; fp32 features are rounded to bf16 on load); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
+  int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
@@ -213,7 +215,10 @@ hipError_t launch_bn_relu_pool(int prec, int pool, const void* z, const float* m
                                const float* gamma, const float* beta, void* out, int B, int H, int W, int C,
                                hipStream_t s);
 hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
-                                const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s);
+                                const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s, float* msum = nullptr);
+hipError_t launch_bn_bwd_meant_saved(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, const float* demb, const float* msum, float* partial, float* sums,
+                                     void* dz, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
                              int B, int K, hipStream_t s, int tc = 0, int tw = 0);
 int bn_bwd_blocks(int B, int H, int W, int* pix_per_block);
@@ -254,6 +259,9 @@ hipError_t launch_fold_pack_conv3x3_split(const float* w, const float* b, const 
                                           hipStream_t s);
 hipError_t launch_cnn2d_block2_split(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_cnn2d_block3_split(const ConvArgs& a, hipStream_t s, int pipe = 1);
+hipError_t launch_pack_conv3x3_dgrad_m16(const float* w, int cin, int cout, uint4* wpack, float* bias, hipStream_t s);
+hipError_t launch_train_dgrad3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
+hipError_t launch_train_dgrad2_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_cnn2d_block3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
                                       int ci_off, int co_off, float* dw, float* db, hipStream_t s);

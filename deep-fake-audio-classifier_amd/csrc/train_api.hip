@@ -38,7 +38,7 @@ constexpr int kWgradWGs = 256;
 
 struct TrainPlan {
   int H1, H2;
-  size_t a1, z2, a2, z3, emb, demb, dz3, da2, dz2, da1, raw, stats, sums, partial, partial_bytes, total;
+  size_t a1, z2, a2, z3, emb, demb, msum, dz3, da2, dz2, da1, raw, stats, sums, partial, partial_bytes, total;
 };
 
 TrainPlan plan_train(int B, int T, int F, int prec) {
@@ -54,6 +54,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   p.z3 = take((size_t)B * p.H2 * F * 128 * es);
   p.emb = take((size_t)B * 128 * F * 4);
   p.demb = take((size_t)B * 128 * F * 4);
+  p.msum = take((size_t)B * 128 * F * 2 * 4);        // block 3: per (b, f, c) mask count and mask*xhat sum over t (bn_relu_meant)
   p.dz3 = take((size_t)B * p.H2 * F * 128 * es);
   p.da2 = take((size_t)B * p.H2 * F * 64 * es);
   p.dz2 = take((size_t)B * p.H1 * F * 64 * es);
@@ -67,6 +68,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   int ppb;
   pb = std::max(pb, (size_t)bn_bwd_blocks(B, p.H1, F, &ppb) * 128 * 2 * 4);  // BN backward partials
   pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 256) * 4);   // weight-gradient partials
+  pb = std::max(pb, ((size_t)B * F / 128 + 1) * 128 * 2 * 4);                // saved-sum BN reduction partials (8 * 16 positions per block)
   p.partial_bytes = pb;
   p.partial = take(pb);
   p.total = off;
@@ -137,11 +139,17 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   const bool fwd3_m16 = prec == DFA_PREC_BF16 && train_conv_variant() != 1;   // 2: pipelined, 0: its compiler-scheduled twin
   if (fwd3_m16)
     DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3_m16(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 128, t3_m16, s, 0));
+  m.train_dgrad_m16 = (prec == DFA_PREC_BF16 && ctx->dgrad_m16) ? 1 : 0;
+  if (m.train_dgrad_m16) {
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad_m16(p[6], 32, 64, m.d2.wpack, m.d2.bias, s));
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad_m16(p[12], 64, 128, m.d3.wpack, m.d3.bias, s));
+  } else {
   DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[6], 32, 64, 0, 64, prec, m.d2.wpack, m.d2.bias, s));
   {  // two Cin halves (see launch_train_dgrad3)
     const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 0, 64, prec, m.d3.wpack, m.d3.bias, s));
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64, 64, prec, m.d3.wpack + (size_t)(64 / 32) * 9 * nkg * 64, m.d3.bias, s));
+  }
   }
   char* ws = (char*)workspace;
   float* partial = (float*)(ws + pl.partial);
@@ -190,7 +198,7 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   StatPtrs s3 = stat_ptrs(ws, pl, 2);
   DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * nstrips, 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, s));
   float* emb = (float*)(ws + pl.emb);
-  DFA_HIP_CHECK(ctx, launch_bn_relu_meant(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], emb, B, pl.H2, F, 128, s));
+  DFA_HIP_CHECK(ctx, launch_bn_relu_meant(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], emb, B, pl.H2, F, 128, s, (float*)(ws + pl.msum)));
   if (embedding) DFA_HIP_CHECK(ctx, hipMemcpyAsync(embedding, emb, (size_t)B * 128 * F * 4, hipMemcpyDeviceToDevice, s));
   DFA_HIP_CHECK(ctx, launch_linear(emb, p[18], p[19], logits, B, 128 * F, s));
   return DFA_OK;
@@ -222,15 +230,16 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   // classifier
   DFA_HIP_CHECK(ctx, launch_linear_bwd(dlogits, p[18], (const float*)(ws + pl.emb), demb, grads[12], grads[13], B, 128 * F, s, 128, F));
   // block 3: BN backward (upstream = mean_T then Linear), weight gradient, data gradient
-  DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_MEANT, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], demb, nullptr, partial, sm3, ws + pl.dz3,
-                                   B, pl.H2, F, 128, dc, s));
+  DFA_HIP_CHECK(ctx, launch_bn_bwd_meant_saved(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], demb, (const float*)(ws + pl.msum), partial,
+                                               sm3, ws + pl.dz3, B, pl.H2, F, 128, s));
   hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm3, grads[10], grads[11], 128);
   DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, 64, 128, ws + pl.dz3, ws + pl.a2, partial, grads[8], grads[9], B, pl.H2, F, kWgradWGs, s));
   {
     ConvArgs a{};
     a.in = ws + pl.dz3; a.wpack = m.d3.wpack; a.bias = m.d3.bias; a.out = ws + pl.da2;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 64; a.relu = 0; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s));
+    if (m.train_dgrad_m16) DFA_HIP_CHECK(ctx, launch_train_dgrad3_m16(a, s, train_conv_variant() != 0));
+    else DFA_HIP_CHECK(ctx, launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s));
   }
   // block 2
   dc.layer = 2;
@@ -242,7 +251,8 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
     ConvArgs a{};
     a.in = ws + pl.dz2; a.wpack = m.d2.wpack; a.bias = m.d2.bias; a.out = ws + pl.da1;
     a.B = B; a.H = pl.H1; a.W = F; a.COUT = 32; a.relu = 0; a.zero_page = ctx->zero_page;
-    DFA_HIP_CHECK(ctx, launch_train_dgrad2(prec, a, s));
+    if (m.train_dgrad_m16) DFA_HIP_CHECK(ctx, launch_train_dgrad2_m16(a, s, train_conv_variant() != 0));
+    else DFA_HIP_CHECK(ctx, launch_train_dgrad2(prec, a, s));
   }
   // block 1 (z1 recomputed from x)
   dc.layer = 1;

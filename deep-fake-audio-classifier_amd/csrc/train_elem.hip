@@ -247,30 +247,87 @@ __global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict_
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ emb,
-                                                            int B, int H, int W, int C) {
+                                                            float* __restrict__ msum, int B, int H, int W, int C) {
+  // msum != nullptr: also save, per (b, f, c), the two sums over t that the BatchNorm BACKWARD reduction of this layer needs --
+  // n = sum_t mask, sx = sum_t mask * xhat (mask and xhat with the backward pass's own formulas) -- as msum[b][f][c][2].
+  // With them dbeta = sum_{b,f} g * n and dgamma = sum_{b,f} g * sx (g = demb / H does not depend on t), so the backward
+  // never re-reads z for its reduction (bn_bwd_reduce_saved_kernel below).
   const int CG = C >> 3;
   const size_t total = (size_t)B * W * CG;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int cg = (int)(i % CG);
   const int f = (int)((i / CG) % W), b = (int)(i / ((size_t)CG * W));
-  float sc[8], sh[8], acc[8];
+  float sc[8], sh[8], acc[8], mu[8], is[8], gm[8], bt[8], cn[8], sx[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    sc[j] = gamma[c] * invstd[c];
-    sh[j] = beta[c] - mean[c] * sc[j];
-    acc[j] = 0.f;
+    mu[j] = mean[c]; is[j] = invstd[c]; gm[j] = gamma[c]; bt[j] = beta[c];
+    sc[j] = gm[j] * is[j];
+    sh[j] = bt[j] - mu[j] * sc[j];
+    acc[j] = 0.f; cn[j] = 0.f; sx[j] = 0.f;
   }
   for (int t = 0; t < H; ++t) {
     float v[8];
     ld8<T>(z + ((((size_t)b * H + t) * W + f) * C + cg * 8), v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+    for (int j = 0; j < 8; ++j) {
+      acc[j] += fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+      if (msum) {
+        const float xh = (v[j] - mu[j]) * is[j];
+        const bool on = fmaf(gm[j], xh, bt[j]) > 0.f;          // bn_bwd_apply_kernel's mask, bit for bit
+        cn[j] += on ? 1.f : 0.f;
+        sx[j] += on ? xh : 0.f;
+      }
+    }
   }
   const float inv_h = 1.0f / (float)H;
 #pragma unroll
   for (int j = 0; j < 8; ++j) emb[((size_t)b * C + cg * 8 + j) * W + f] = acc[j] * inv_h;
+  if (msum) {
+    float* o = msum + (((size_t)b * W + f) * C + cg * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) *reinterpret_cast<float4*>(o + 2 * j) = make_float4(cn[j], sx[j], cn[j + 1], sx[j + 1]);
+  }
+}
+
+// BatchNorm backward reduction of the mean-over-T layer from the forward's saved sums: partial[block][C][2] with
+// S1 = sum g*n, S2 = sum g*sx over this block's (b, f) positions, g = demb[b][f][c] / H.  Reads 3 floats per (b, f, c)
+// instead of z [B][H][W][C].
+__global__ __launch_bounds__(256) void bn_bwd_reduce_saved_kernel(const float* __restrict__ demb, const float* __restrict__ msum,
+                                                                  float* __restrict__ partial, size_t npos, int C, float inv_h,
+                                                                  int pos_per_block) {
+  extern __shared__ float red[];  // [PL][C][2]
+  const int CG = C >> 3, PL = 256 / CG;
+  const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+  const size_t p0 = (size_t)blockIdx.x * pos_per_block;
+  const size_t p1 = (p0 + pos_per_block < npos) ? p0 + pos_per_block : npos;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (pl < PL)
+    for (size_t p = p0 + pl; p < p1; p += PL) {
+      float d[8];
+      ld8<float>(demb + p * C + cg * 8, d);
+      const float* m = msum + (p * C + cg * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const float4 q = *reinterpret_cast<const float4*>(m + 2 * j);
+        const float g0 = d[j] * inv_h, g1 = d[j + 1] * inv_h;
+        s1[j] = fmaf(g0, q.x, s1[j]); s2[j] = fmaf(g0, q.y, s2[j]);
+        s1[j + 1] = fmaf(g1, q.z, s1[j + 1]); s2[j + 1] = fmaf(g1, q.w, s2[j + 1]);
+      }
+    }
+  if (pl < PL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(pl * C + cg * 8 + j) * 2] = s1[j]; red[(pl * C + cg * 8 + j) * 2 + 1] = s2[j]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 2; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * C * 2 + e];
+    partial[(size_t)blockIdx.x * C * 2 + e] = s;
+  }
 }
 
 // ---- backward of Linear(K,1): demb[b][j] = dlogit[b]*w[j];  dw[j] = sum_b dlogit[b]*emb[b][j];  db = sum_b dlogit[b]
@@ -569,13 +626,41 @@ hipError_t launch_bn_relu_pool(int prec, int pool, const void* z, const float* m
 }
 
 hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
-                                const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s) {
+                                const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s, float* msum) {
   const size_t total = (size_t)B * W * (C / 8);
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(bn_relu_meant_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, emb, B, H, W, C);
+    hipLaunchKernelGGL(bn_relu_meant_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, emb, msum, B, H, W, C);
   else
-    hipLaunchKernelGGL(bn_relu_meant_kernel<float>, grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, emb, B, H, W, C);
+    hipLaunchKernelGGL(bn_relu_meant_kernel<float>, grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, emb, msum, B, H, W, C);
+  return hipGetLastError();
+}
+
+// BatchNorm backward of the mean-over-T layer with the reduction taken from the forward's saved sums (msum[B][W][C][2]):
+// reduce (3 floats per position) -> fixed-order second stage -> the usual apply pass (z -> dz).
+hipError_t launch_bn_bwd_meant_saved(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, const float* demb, const float* msum, float* partial, float* sums,
+                                     void* dz, int B, int H, int W, int C, hipStream_t s) {
+  const size_t npos = (size_t)B * W;
+  const int PL = 256 / (C / 8);
+  const int ppb = 8 * PL;
+  const int nblk = (int)((npos + ppb - 1) / ppb);
+  const size_t lds = (size_t)PL * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_saved_kernel, dim3(nblk), dim3(256), lds, s, demb, msum, partial, npos, C, 1.0f / (float)H, ppb);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s, nullptr);
+  if (e != hipSuccess) return e;
+  const int ppb2 = 16 * PL;
+  dim3 g2((unsigned)(((size_t)B * H * W + ppb2 - 1) / ppb2));
+  const float inv_n = (float)(1.0 / ((double)B * H * W));
+  DropCfg dc{};
+  if (prec == DFA_PREC_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, SRC_MEANT>), g2, dim3(256), 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, sums,
+                       demb, (const bf16_t*)nullptr, (bf16_t*)dz, B, H, W, C, dc, inv_n, ppb2);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, SRC_MEANT>), g2, dim3(256), 0, s, (const float*)z, mean, invstd, gamma, beta, sums,
+                       demb, (const float*)nullptr, (float*)dz, B, H, W, C, dc, inv_n, ppb2);
   return hipGetLastError();
 }
 

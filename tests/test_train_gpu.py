@@ -423,3 +423,41 @@ def test_train_cae_cli_end_to_end(tmp_path):
         assert (tmp_path / "cae" / f).exists()
     blob = load_checkpoint(str(tmp_path / "cae" / "cae_best.pt"))
     assert "encoder.12.weight" in blob["model_state"] and "decoder.9.bias" in blob["model_state"]
+
+
+def test_bf16_single_launch_data_gradients_match_two_launch_path(golden):
+    """Round 2: the bf16 data-gradient convolutions run as ONE launch each of the 16x16x32 kernel (conv_split.hip, plain-bf16
+    form; block 3 with all 128 input channels, no fp32 partial sums).  Same bf16 operands, fp32 accumulation in another
+    order: the stored bf16 da differs from the 32x32x16 / two-launch path by rounding flips only, and so do the gradients
+    downstream of it; parameters upstream of the first dgrad (block 3, classifier) are bit-identical."""
+    from dfa_amd import _lib
+    _, g = golden("cnn2d_train")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(19)
+    cases = [(torch.from_numpy(g["ls0.x"]).transpose(1, 2), torch.from_numpy(g["ls0.y"])),
+             (torch.randn(24, 180, 97, generator=gen).transpose(1, 2), (torch.rand(24, generator=gen) > 0.5).float()),
+             (torch.randn(3, 65, 21, generator=gen).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0]))]
+
+    def grads(flag, x, y):
+        from dfa_amd.model import CNN2D
+        ctx.set_option("dgrad_m16", flag)
+        if x.shape[2] == 180:
+            model = _fresh_model(g, precision="bf16")
+        else:
+            torch.manual_seed(4)
+            model = CNN2D(in_features=x.shape[2], dropout=0.0, precision="bf16").to("cuda").train()
+        loss = torch.nn.BCEWithLogitsLoss()(model(x.to("cuda")).squeeze(-1), y.to("cuda"))
+        loss.backward()
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    try:
+        for x, y in cases:
+            new, old = grads(1, x, y), grads(0, x, y)
+            for n in new:
+                if n.startswith("conv.10") or n.startswith("conv.11") or n.startswith("classifier"):
+                    assert torch.equal(new[n], old[n]), n
+                elif n not in NOISE_KEYS:
+                    scale = max(float(old[n].abs().max()), 1e-6)
+                    assert float((new[n] - old[n]).abs().max()) <= 3e-2 * scale, (n, float((new[n] - old[n]).abs().max()) / scale)
+    finally:
+        ctx.set_option("dgrad_m16", 1)
