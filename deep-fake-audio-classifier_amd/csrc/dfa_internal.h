@@ -50,6 +50,7 @@ struct Cnn2dState {
   PackedConv t2, t3, d2, d3;              // raw forward images and data-gradient images
   DropCfg train_drop{};
   int train_prec = -1, train_B = 0, train_T = 0;
+  int train_c1_fused = 0;                 // the forward left XX / Xs behind for the one-pass conv1 backward
   int train_dgrad_m16 = 0;                // the d2/d3 images are in the 16x16x32 order of conv_split.hip (bf16 mode)
 };
 
@@ -92,6 +93,7 @@ struct dfa_ctx {
   int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
   int fuse_conv1 = 1;          // bf16 mode: blocks 1 and 2 in one kernel (conv12_fused.hip; fp32 features are rounded to bf16 on load); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
+  int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
@@ -234,6 +236,9 @@ hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, 
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
                               int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1);
+hipError_t launch_conv1_bwd_finalize(const float* rec, const float* xxs, const float* w, const float* bconv, const float* mean,
+                                     const float* invstd, const float* gamma, double n, float* dw, float* db, float* dgamma,
+                                     float* dbeta, hipStream_t s);
 // cae_train.hip
 hipError_t launch_pixel_unshuffle(int prec, const void* dz, void* zp, int B, int H, int W, int Wo, int C, hipStream_t s);
 hipError_t launch_convt_w_to_q(const float* w, float* wq, int cin, int cout, hipStream_t s);

@@ -14,7 +14,7 @@ hipError_t launch_train_fwd2(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_train_fwd3(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
 hipError_t launch_train_dgrad2(int prec, const ConvArgs& a, hipStream_t s);
-enum { C1M_STATS = 0, C1M_BWD_REDUCE = 1, C1M_WGRAD = 2 };
+enum { C1M_STATS = 0, C1M_BWD_REDUCE = 1, C1M_WGRAD = 2, C1M_BWD_FUSED = 3, C1M_STATS_XX = 4 };
 enum { SRC_MEANT = 0, SRC_POOL = 1 };
 
 // dgamma = S2, dbeta = S1 from sums[C][2]
@@ -61,10 +61,10 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   p.da1 = take((size_t)B * p.H1 * F * 32 * es);
   p.raw = take((size_t)B * p.H2 * F * 64 * 4);
   p.stats = take((32 + 64 + 128) * 3 * 4);          // mean | var | invstd per layer
-  p.sums = take((32 + 64 + 128) * 2 * 4 + 320 * 4);  // (S1,S2) per layer + conv1 wgrad record
+  p.sums = take((32 + 64 + 128) * 2 * 4 + 352 * 4 + 96 * 4);  // (S1,S2) per layer + conv1 backward record [32][11] + XX[9][9] | Xs[9]
   const int nstrips = (F + 31) / 32;
   size_t pb = (size_t)B * nstrips * 128 * 2 * 4;                              // conv stats partials
-  pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 320 * 4);   // conv1 passes + 2nd-level scratch
+  pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 352 * 4);   // conv1 passes + 2nd-level scratch
   int ppb;
   pb = std::max(pb, (size_t)bn_bwd_blocks(B, p.H1, F, &ppb) * 128 * 2 * 4);  // BN backward partials
   pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 256) * 4);   // weight-gradient partials
@@ -165,9 +165,15 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   }
   // ---- block 1
   StatPtrs s1 = stat_ptrs(ws, pl, 0);
-  DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, nullptr, nullptr,
-                                        nullptr, nullptr, prec, partial, B, T, F, dc, s));
-  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, s));
+  m.train_c1_fused = ctx->conv1_bwd_fused ? 1 : 0;
+  const int nb1f = conv1_train_blocks(B, T, F);
+  DFA_HIP_CHECK(ctx, launch_conv1_train(m.train_c1_fused ? C1M_STATS_XX : C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1],
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prec, partial, B, T, F, dc, s));
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nb1f, 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, s));
+  if (m.train_c1_fused) {   // XX[9][9] | Xs[9] (block records of 96 floats behind the [32][2] records) -> the sums region, for backward
+    float* xxs = (float*)(ws + pl.sums) + 2 * (32 + 64 + 128) + 352;
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial + (size_t)nb1f * 64, nb1f, 96, 1.0f, xxs, s, partial + (size_t)nb1f * 160));
+  }
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], s1.mean, s1.var, m.tw1, m.tb1, 32, s));
   dc.layer = 1;
   DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.tw1, m.tb1, ws + pl.a1, prec, B, T, F, s, &dc));
@@ -257,6 +263,16 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   // block 1 (z1 recomputed from x)
   dc.layer = 1;
   const int nb1 = conv1_train_blocks(B, T, F);
+  if (m.train_c1_fused) {
+    DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_FUSED, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
+                                          nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s));
+    float* rec = c1rec;                       // [32][11]
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 352, 1.0f, rec, s, partial + (size_t)nb1 * 352));
+    DFA_HIP_CHECK(ctx, launch_conv1_bwd_finalize(rec, c1rec + 352, p[0], p[1], s1.mean, s1.invstd, p[2], (double)B * T * F, grads[0], grads[1],
+                                                 grads[2], grads[3], s));
+    DFA_HIP_CHECK(ctx, hipGetLastError());
+    return DFA_OK;
+  }
   DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
                                         nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s));
   float* scratch = partial + (size_t)nb1 * 320;

@@ -461,3 +461,47 @@ def test_bf16_single_launch_data_gradients_match_two_launch_path(golden):
                     assert float((new[n] - old[n]).abs().max()) <= 3e-2 * scale, (n, float((new[n] - old[n]).abs().max()) / scale)
     finally:
         ctx.set_option("dgrad_m16", 1)
+
+
+def test_one_pass_conv1_backward_matches_two_pass_path(golden):
+    """Round 2: block 1's backward is ONE pass over da1 (A = sum dy*x_tap, S1, S2) plus a 9 x 9 moment matrix of x taken by
+    the forward's statistics pass; dW1 follows by algebra (train_conv1.hip).  It must agree with the reduce + weight-gradient
+    two-pass form to fp32 summation noise, at the golden size, at a ragged width and at a batch that uses the second
+    reduction level, in fp32 and bf16 storage."""
+    from dfa_amd import _lib
+    from dfa_amd.model import CNN2D
+    _, g = golden("cnn2d_train")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(23)
+    cases = [(torch.from_numpy(g["ls0.x"]).transpose(1, 2), torch.from_numpy(g["ls0.y"])),
+             ((torch.randn(3, 65, 21, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0])),
+             ((torch.randn(200, 180, 161, generator=gen) * 3.2 - 0.07).transpose(1, 2), (torch.rand(200, generator=gen) > 0.5).float())]
+
+    def grads(flag, prec, x, y, drop):
+        ctx.set_option("conv1_bwd_fused", flag)
+        torch.manual_seed(4)
+        model = CNN2D(in_features=x.shape[2], dropout=drop, precision=prec).to("cuda").train()
+        model._drop_seed = 77
+        with torch.no_grad():
+            model.classifier.weight.mul_(30.0)
+        loss = torch.nn.BCEWithLogitsLoss()(model(x.to("cuda")).squeeze(-1), y.to("cuda"))
+        loss.backward()
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    try:
+        for prec in ("fp32", "bf16"):
+            for drop in (0.0, 0.2):
+                for x, y in cases:
+                    new, old = grads(1, prec, x, y, drop), grads(0, prec, x, y, drop)
+                    for n in new:
+                        if n in ("conv.0.weight", "conv.1.weight", "conv.1.bias"):
+                            scale = max(float(old[n].abs().max()), 1e-6)
+                            err = float((new[n] - old[n]).abs().max())
+                            assert err <= 2e-4 * scale + 1e-7, (prec, drop, tuple(x.shape), n, err / scale)
+                        elif n == "conv.0.bias":
+                            floor = 1e-4 * float(old["conv.0.weight"].abs().max()) + 1e-6
+                            assert float(new[n].abs().max()) < floor, (prec, n)
+                        else:
+                            assert torch.equal(new[n], old[n]), n      # nothing else changes
+    finally:
+        ctx.set_option("conv1_bwd_fused", 1)
