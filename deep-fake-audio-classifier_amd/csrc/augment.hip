@@ -4,7 +4,9 @@
 //   out[b][t][f] = keep[f] * mask(x[b][(t - shift) mod T][f]) + std * N(0,1)
 // The random PARAMETERS (mask spans, shift, per-dim keep mask) are drawn on the host exactly as the reference draws them
 // (one draw per batch, Python `random` / the torch generator); only the jitter noise comes from the in-kernel Philox
-// stream (4 normals per call, Box-Muller) -- a torch.randn_like stream cannot be reproduced on another device anyway.
+// stream (one normal per element, Box-Muller) -- a torch.randn_like stream cannot be reproduced on another device anyway.
+// The element formula lives in rng.h (AugCfg / aug_apply): the training kernels that read x fold the SAME function into
+// their loads (dfa_cnn2d_set_train_augment), so this stand-alone pass and the folded form give identical batches.
 #include "dfa_internal.h"
 #include "rng.h"
 
@@ -13,12 +15,8 @@ namespace dfa {
 struct AugArgs {
   const void* x; void* out;
   long long sxb, sxt, sxf, sob, sot, sof;   // element strides of input and output
-  int B, T, F;
-  int shift;                                // torch.roll(shifts=shift, dims=1)
-  const float* keep;                        // [F] multiplicative mask or null
-  int tm_start, tm_len, fm_start, fm_len;   // zeroed spans (len 0 = none), applied BEFORE the shift like the reference
-  float std;
-  uint64_t seed, offset;
+  int B;
+  AugCfg cfg;                               // rng.h: the same definition the training kernels fold into their loads
 };
 
 __device__ __forceinline__ float aug_ld(const float* p) { return *p; }
@@ -29,7 +27,7 @@ __device__ __forceinline__ void aug_st(bf16_t* p, float v) { *p = float_to_bf16(
 // thread = 4 consecutive elements of the output's contiguous dimension (TFAST: that is t, else f)
 template <typename TI, typename TO, bool TFAST>
 __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
-  const int T = a.T, F = a.F;
+  const int T = a.cfg.T, F = a.cfg.F;
   const int inner = TFAST ? T : F, outer = TFAST ? F : T;
   const int ngrp = (inner + 3) >> 2;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -38,20 +36,6 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
   const int g = (int)(gid % ngrp);
   const long long rest = gid / ngrp;
   const int o = (int)(rest % outer), b = (int)(rest / outer);
-  float nz[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.std > 0.f) {
-    const uint64_t q = (uint64_t)gid + a.offset;
-    const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), 0x41554721u, 0u),
-                                  make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32)));
-    // Box-Muller on two pairs of uniforms in (0, 1]
-    const float u0 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
-    const float m0 = sqrtf(-2.0f * __logf(u0)), m1 = sqrtf(-2.0f * __logf(u2));
-    float s0, c0, s1, c1;
-    __sincosf(6.28318530717958648f * u1, &s0, &c0);
-    __sincosf(6.28318530717958648f * u3, &s1, &c1);
-    nz[0] = m0 * c0 * a.std; nz[1] = m0 * s0 * a.std; nz[2] = m1 * c1 * a.std; nz[3] = m1 * s1 * a.std;
-  }
   const TI* xb = (const TI*)a.x + (long long)b * a.sxb;
   TO* ob = (TO*)a.out + (long long)b * a.sob;
 #pragma unroll
@@ -59,20 +43,15 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     const int i = 4 * g + e;
     if (i >= inner) break;
     const int t = TFAST ? i : o, f = TFAST ? o : i;
-    int ts = t - a.shift;                     // source frame of torch.roll
-    ts %= T;
-    if (ts < 0) ts += T;
-    const bool masked = (a.tm_len > 0 && ts >= a.tm_start && ts < a.tm_start + a.tm_len) ||
-                        (a.fm_len > 0 && f >= a.fm_start && f < a.fm_start + a.fm_len);
-    float v = masked ? 0.f : aug_ld(xb + (long long)ts * a.sxt + (long long)f * a.sxf);
-    if (a.keep) v *= a.keep[f];
-    aug_st(ob + (long long)t * a.sot + (long long)f * a.sof, v + nz[e]);
+    const int ts = aug_src_t(a.cfg, t);
+    const float xraw = aug_ld(xb + (long long)ts * a.sxt + (long long)f * a.sxf);
+    aug_st(ob + (long long)t * a.sot + (long long)f * a.sof, aug_apply(a.cfg, xraw, b, t, f));
   }
 }
 
 hipError_t launch_augment(const AugArgs& a, int x_dtype, int out_dtype, hipStream_t s) {
   const bool tfast = (a.sot == 1);
-  const int inner = tfast ? a.T : a.F, outer = tfast ? a.F : a.T;
+  const int inner = tfast ? a.cfg.T : a.cfg.F, outer = tfast ? a.cfg.F : a.cfg.T;
   const long long total = (long long)a.B * outer * ((inner + 3) >> 2);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
 #define DFA_AUG(TI, TO)                                                                        \
@@ -109,9 +88,10 @@ extern "C" int dfa_augment_batch(dfa_ctx* ctx, const void* x, int x_dtype, int B
   a.x = x; a.out = out;
   a.sxb = stride_b; a.sxt = stride_t; a.sxf = stride_f;
   a.sob = out_stride_b; a.sot = out_stride_t; a.sof = out_stride_f;
-  a.B = B; a.T = T; a.F = F; a.shift = shift; a.keep = keep_f;
-  a.tm_start = tmask_start; a.tm_len = tmask_len; a.fm_start = fmask_start; a.fm_len = fmask_len;
-  a.std = jitter_std; a.seed = seed; a.offset = offset;
+  a.B = B;
+  a.cfg.on = 1; a.cfg.T = T; a.cfg.F = F; a.cfg.shift = ((shift % T) + T) % T; a.cfg.keep = keep_f;
+  a.cfg.tm_start = tmask_start; a.cfg.tm_len = tmask_len; a.cfg.fm_start = fmask_start; a.cfg.fm_len = fmask_len;
+  a.cfg.std = jitter_std; a.cfg.seed = seed; a.cfg.offset = offset;
   DFA_HIP_CHECK(ctx, launch_augment(a, x_dtype, out_dtype, ctx->stream));
   return DFA_OK;
 }

@@ -35,7 +35,7 @@ template <typename TX, typename TO>
 __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __restrict__ x, int64_t sb, int64_t st,
                                                                    int64_t sf, const float* __restrict__ w1,
                                                                    const float* __restrict__ b1, TO* __restrict__ out,
-                                                                   int T, int F, int Ho, DropCfg dc) {
+                                                                   int T, int F, int Ho, DropCfg dc, AugCfg aug) {
   __shared__ float xs[2][C1_XR][C1_XC + 1];
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
       const int t = 2 * i0 - 1 + rr, f = f_base + cc;
       // branch-free: always load from a clamped in-image address, zero afterwards -- the NX loads issue back to back
       const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
-      xr[k] = xb[(int64_t)tc * st + (int64_t)fc * sf];   // raw bits only: the first USE (and its wait) is in store_tile
+      xr[k] = xb[(int64_t)aug_src_t(aug, tc) * st + (int64_t)fc * sf];   // raw bits only: the first USE (and its wait) is in store_tile
     }
   };
   auto store_tile = [&](int buf, int i0, const TX* xr) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
       if (t_fast) { cc = e / C1_XR; rr = e - cc * C1_XR; } else { rr = e / C1_XC; cc = e - rr * C1_XC; }
       const int t = 2 * i0 - 1 + rr, f = f_base + cc;
       const bool ok = t >= 0 && t < T && f >= 0 && f < F;     // conv zero padding
-      if (e < C1_XR * C1_XC) xs[buf][rr][cc] = ok ? load_x<TX>(&xr[k]) : 0.f;
+      if (e < C1_XR * C1_XC) xs[buf][rr][cc] = ok ? aug_apply(aug, load_x<TX>(&xr[k]), b, t, f) : 0.f;   // train: augmentation folded in
     }
   };
   const int q = tid & 3, pl = tid >> 2;   // channel octet, pixel lane (0..63)
@@ -164,9 +164,11 @@ __global__ __launch_bounds__(256) void conv1_bn_relu_poolh2_kernel(const TX* __r
 
 hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
                         const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s,
-                        const DropCfg* drop) {
+                        const DropCfg* drop, const AugCfg* augp) {
   DropCfg dc{};
   if (drop) dc = *drop;
+  AugCfg aug{};
+  if (augp) aug = *augp;
   const int Ho = T / 2;
   // few row-tile walkers per (utterance, column tile) once the batch alone fills the chip; more for small batches
   const int ntiles = (Ho + C1_TI - 1) / C1_TI, ncols = (F + C1_TF - 1) / C1_TF;
@@ -176,24 +178,24 @@ hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int6
   if (out_prec == DFA_PREC_BF16X3) {
     if (x_dtype == DFA_DTYPE_F32)
       hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, split_t>), grid, block, 0, s, (const float*)x, sb, st, sf, w1,
-                         b1, (split_t*)out, T, F, Ho, dc);
+                         b1, (split_t*)out, T, F, Ho, dc, aug);
     else
       hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<bf16_t, split_t>), grid, block, 0, s, (const bf16_t*)x, sb, st, sf,
-                         w1, b1, (split_t*)out, T, F, Ho, dc);
+                         w1, b1, (split_t*)out, T, F, Ho, dc, aug);
     return hipGetLastError();
   }
   if (x_dtype == DFA_DTYPE_F32 && out_prec == DFA_PREC_F32)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, float>), grid, block, 0, s, (const float*)x, sb, st, sf, w1,
-                       b1, (float*)out, T, F, Ho, dc);
+                       b1, (float*)out, T, F, Ho, dc, aug);
   else if (x_dtype == DFA_DTYPE_F32 && out_prec == DFA_PREC_BF16)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, sb, st, sf,
-                       w1, b1, (bf16_t*)out, T, F, Ho, dc);
+                       w1, b1, (bf16_t*)out, T, F, Ho, dc, aug);
   else if (x_dtype == DFA_DTYPE_BF16 && out_prec == DFA_PREC_F32)
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, sb, st, sf,
-                       w1, b1, (float*)out, T, F, Ho, dc);
+                       w1, b1, (float*)out, T, F, Ho, dc, aug);
   else
     hipLaunchKernelGGL((conv1_bn_relu_poolh2_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, sb, st, sf,
-                       w1, b1, (bf16_t*)out, T, F, Ho, dc);
+                       w1, b1, (bf16_t*)out, T, F, Ho, dc, aug);
   return hipGetLastError();
 }
 

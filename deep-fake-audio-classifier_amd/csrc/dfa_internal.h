@@ -49,6 +49,8 @@ struct Cnn2dState {
   float *tw1 = nullptr, *tb1 = nullptr;   // conv1 folded with the current batch statistics
   PackedConv t2, t3, d2, d3;              // raw forward images and data-gradient images
   DropCfg train_drop{};
+  AugCfg aug_armed{};                     // dfa_cnn2d_set_train_augment: consumed by the next forward_train
+  AugCfg train_aug{};                     // the augmentation of the forward_train in flight (its backward re-reads x through it)
   int train_prec = -1, train_B = 0, train_T = 0;
   int train_c1_fused = 0;                 // the forward left XX / Xs behind for the one-pass conv1 backward
   int train_dgrad_m16 = 0;                // the d2/d3 images are in the 16x16x32 order of conv_split.hip (bf16 mode)
@@ -167,7 +169,7 @@ hipError_t launch_gemm_f32(int a_bf16, const void* A, int64_t sam, int64_t sak, 
 // conv1.hip
 hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w1,
                         const float* b1, void* out, int out_prec, int B, int T, int F, hipStream_t s,
-                        const DropCfg* drop = nullptr);
+                        const DropCfg* drop = nullptr, const AugCfg* aug = nullptr);
 // linear.hip
 hipError_t launch_linear(const float* emb, const float* w, const float* bias, float* logits, int B, int K,
                          hipStream_t s);
@@ -235,7 +237,7 @@ int conv1_train_blocks(int B, int T, int F);
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
-                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1);
+                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1, const AugCfg* aug = nullptr);
 hipError_t launch_conv1_bwd_finalize(const float* rec, const float* xxs, const float* w, const float* bconv, const float* mean,
                                      const float* invstd, const float* gamma, double n, float* dw, float* db, float* dgamma,
                                      float* dbeta, hipStream_t s);

@@ -50,4 +50,44 @@ __device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, floa
   }
 }
 
+// ---- train-time feature augmentation folded into the loads of the kernels that read x (src/train.py:68-69 applies
+// src/augmentation.py:5-186 to the batch before the model).  The augmented tensor is
+//   xa[b][t][f] = keep[f] * mask(x[b][(t - shift) mod T][f]) + std * N(0,1)(seed, offset + (b*T + t)*F + f)
+// (mask spans refer to frames / feature dims BEFORE the shift: the reference's op order time mask, feature mask, roll,
+// channel drop, jitter).  on = 0: identity.
+struct AugCfg {
+  int on;
+  int T, F;
+  int shift;                                // normalised into [0, T)
+  const float* keep;                        // [F] multiplicative mask or null
+  int tm_start, tm_len, fm_start, fm_len;   // zeroed spans (len 0 = none)
+  float std;
+  uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float aug_noise(const AugCfg& a, uint64_t idx) {
+  const uint64_t q = idx + a.offset;
+  const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), 0x41554721u, 0u),
+                                make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32)));
+  const float u0 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * __logf(u0)) * __cosf(6.28318530717958648f * u1) * a.std;   // Box-Muller, one normal per element
+}
+// source frame of output frame t (torch.roll(shifts = shift, dims = 1)); t in [0, T)
+__device__ __forceinline__ int aug_src_t(const AugCfg& a, int t) {
+  if (!a.on) return t;
+  int ts = t - a.shift;
+  return ts < 0 ? ts + a.T : ts;
+}
+// finish an element: xraw = x[b][aug_src_t(t)][f] as float
+__device__ __forceinline__ float aug_apply(const AugCfg& a, float xraw, int b, int t, int f) {
+  if (!a.on) return xraw;
+  const int ts = aug_src_t(a, t);
+  const bool masked = (a.tm_len > 0 && ts >= a.tm_start && ts < a.tm_start + a.tm_len) ||
+                      (a.fm_len > 0 && f >= a.fm_start && f < a.fm_start + a.fm_len);
+  float v = masked ? 0.f : xraw;
+  if (a.keep) v *= a.keep[f];
+  if (a.std > 0.f) v += aug_noise(a, ((uint64_t)b * a.T + t) * a.F + f);
+  return v;
+}
+
 }  // namespace dfa

@@ -165,10 +165,18 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   }
   // ---- block 1
   StatPtrs s1 = stat_ptrs(ws, pl, 0);
+  // augmentation armed by dfa_cnn2d_set_train_augment: one-shot, folded into the three kernels that read x
+  m.train_aug = m.aug_armed;
+  m.aug_armed = AugCfg{};
+  if (m.train_aug.on) {
+    if (m.train_aug.T != T || m.train_aug.F != F)
+      return fail(ctx, DFA_E_BAD_SHAPE, "the armed augmentation was drawn for [T=%d, F=%d], the batch is [T=%d, F=%d]", m.train_aug.T, m.train_aug.F, T, F);
+  }
+  const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
   m.train_c1_fused = ctx->conv1_bwd_fused ? 1 : 0;
   const int nb1f = conv1_train_blocks(B, T, F);
   DFA_HIP_CHECK(ctx, launch_conv1_train(m.train_c1_fused ? C1M_STATS_XX : C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1],
-                                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prec, partial, B, T, F, dc, s));
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prec, partial, B, T, F, dc, s, 1, aug));
   DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nb1f, 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, s));
   if (m.train_c1_fused) {   // XX[9][9] | Xs[9] (block records of 96 floats behind the [32][2] records) -> the sums region, for backward
     float* xxs = (float*)(ws + pl.sums) + 2 * (32 + 64 + 128) + 352;
@@ -176,7 +184,7 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   }
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], s1.mean, s1.var, m.tw1, m.tb1, 32, s));
   dc.layer = 1;
-  DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.tw1, m.tb1, ws + pl.a1, prec, B, T, F, s, &dc));
+  DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.tw1, m.tb1, ws + pl.a1, prec, B, T, F, s, &dc, aug));
   // ---- block 2
   const int nstrips = (F + 31) / 32;
   {
@@ -263,9 +271,10 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   // block 1 (z1 recomputed from x)
   dc.layer = 1;
   const int nb1 = conv1_train_blocks(B, T, F);
+  const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
   if (m.train_c1_fused) {
     DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_FUSED, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
-                                          nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s));
+                                          nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug));
     float* rec = c1rec;                       // [32][11]
     DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 352, 1.0f, rec, s, partial + (size_t)nb1 * 352));
     DFA_HIP_CHECK(ctx, launch_conv1_bwd_finalize(rec, c1rec + 352, p[0], p[1], s1.mean, s1.invstd, p[2], (double)B * T * F, grads[0], grads[1],
@@ -274,15 +283,35 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
     return DFA_OK;
   }
   DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
-                                        nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s));
+                                        nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug));
   float* scratch = partial + (size_t)nb1 * 320;
   DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm1, s, scratch));
   hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm1, grads[2], grads[3], 32);
   DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_WGRAD, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
-                                        sm1, ws + pl.da1, prec, partial, B, T, F, dc, s));
+                                        sm1, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug));
   DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, c1rec, s, scratch));
   hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, c1rec, grads[0], grads[1]);
   DFA_HIP_CHECK(ctx, hipGetLastError());
+  return DFA_OK;
+}
+
+int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
+                                int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
+                                uint64_t offset) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  Cnn2dState& m = ctx->cnn2d;
+  m.aug_armed = AugCfg{};
+  if (!enable) return DFA_OK;
+  if (T < 1 || F < 1) return fail(ctx, DFA_E_BAD_SHAPE, "bad augmentation shape [T=%d, F=%d]", T, F);
+  if (tmask_len < 0 || fmask_len < 0 || tmask_start < 0 || fmask_start < 0 || tmask_start + tmask_len > T ||
+      fmask_start + fmask_len > F)
+    return fail(ctx, DFA_E_BAD_SHAPE, "mask span outside the batch");
+  if (!(jitter_std >= 0.f)) return fail(ctx, DFA_E_BAD_SHAPE, "jitter std must be >= 0");
+  AugCfg a{};
+  a.on = 1; a.T = T; a.F = F; a.shift = ((shift % T) + T) % T; a.keep = keep_f;
+  a.tm_start = tmask_start; a.tm_len = tmask_len; a.fm_start = fmask_start; a.fm_len = fmask_len;
+  a.std = jitter_std; a.seed = seed; a.offset = offset;
+  m.aug_armed = a;
   return DFA_OK;
 }
 

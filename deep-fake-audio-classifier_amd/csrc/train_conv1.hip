@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ sums,
                                                           const T* __restrict__ da1, float* __restrict__ partial, int Tt,
-                                                          int F, DropCfg dc, float inv_n) {
+                                                          int F, DropCfg dc, float inv_n, AugCfg aug) {
   constexpr int NV = (MODE == C1M_WGRAD) ? 10 : (MODE == C1M_BWD_FUSED) ? 11 : 2;
   constexpr bool STATS = (MODE == C1M_STATS || MODE == C1M_STATS_XX);
   // STATS_XX: thread q also owns rows j = q, q+4, q+8 of XX[j][k] = sum x_j*x_k, and thread q == 1 the tap sums Xs[k]
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void conv1_train_kernel(const TX* __restrict__
       int rr, cc;
       if (t_fast) { cc = e / (C1T_R + 2); rr = e - cc * (C1T_R + 2); } else { rr = e / (C1T_C + 2); cc = e - rr * (C1T_C + 2); }
       const int t = t0 - 1 + rr, f = f0 - 1 + cc;
-      xs[rr][cc] = (t >= 0 && t < Tt && f >= 0 && f < F) ? ldx<TX>(xb + (int64_t)t * st + (int64_t)f * sf) : 0.f;
+      xs[rr][cc] = (t >= 0 && t < Tt && f >= 0 && f < F)
+                       ? aug_apply(aug, ldx<TX>(xb + (int64_t)aug_src_t(aug, t) * st + (int64_t)f * sf), b, t, f) : 0.f;
     }
     __syncthreads();
 #pragma unroll 1
@@ -273,17 +274,19 @@ int conv1_train_blocks(int B, int T, int F) { (void)T; return B * C1T_GY * ((F +
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
-                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw) {
+                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw, const AugCfg* augp) {
+  AugCfg aug{};
+  if (augp) aug = *augp;
   dim3 grid((F + C1T_C - 1) / C1T_C, C1T_GY, B), block(256);
   const float inv_n = (float)(1.0 / ((double)B * T * F));
 #define DFA_C1T(TXX, TT, MODE)                                                                                        \
   do {                                                                                                                 \
     if (poolw == 2)                                                                                                    \
       hipLaunchKernelGGL((conv1_train_kernel<TXX, TT, MODE, 2>), grid, block, 0, s, (const TXX*)x, sb, st, sf, w, bconv, \
-                         mean, invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n);                  \
+                         mean, invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n, aug);                  \
     else                                                                                                               \
       hipLaunchKernelGGL((conv1_train_kernel<TXX, TT, MODE, 1>), grid, block, 0, s, (const TXX*)x, sb, st, sf, w, bconv, \
-                         mean, invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n);                  \
+                         mean, invstd, gamma, beta, sums, (const TT*)da1, partial, T, F, dc, inv_n, aug);                  \
   } while (0)
 #define DFA_C1T_MODES(TXX, TT)                                                                                        \
   do {                                                                                                                 \

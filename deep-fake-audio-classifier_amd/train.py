@@ -75,10 +75,12 @@ def train_one_epoch_native(trainer, batcher, augment_fn=None, swap_tf: bool = Tr
     return (float(total.item()) / count) if count else None
 
 
-def build_augment_fn(args, fused: bool = False):
-    """fused = True (GPU training): the whole pipeline as one HIP pass (augmentation.FusedAugment), same parameter draws."""
+def build_augment_fn(args, fused: bool = False, fold: bool = False):
+    """fused = True (GPU training): the whole pipeline as one HIP pass (augmentation.FusedAugment), same parameter draws;
+    fold = True (CNN2D): not even a pass -- the parameters are armed on the context and the training kernels that read x
+    apply them in their loads."""
     if fused and (args.spec_augment or args.time_shift or args.channel_drop or args.gaussian_jitter):
-        return FusedAugment(spec_augment=args.spec_augment, time_mask_ratio=args.time_mask_ratio,
+        return FusedAugment(fold=fold, spec_augment=args.spec_augment, time_mask_ratio=args.time_mask_ratio,
                             feature_mask=args.feature_mask, feature_mask_ratio=args.feature_mask_ratio,
                             time_shift=args.time_shift, time_shift_ratio=args.time_shift_ratio,
                             channel_drop=args.channel_drop, channel_drop_prob=args.channel_drop_prob,
@@ -182,7 +184,8 @@ def main(argv=None):
     model._drop_seed = dfa_dist.rank_seed(args.seed if args.seed else torch.initial_seed(), rank)
     weight_decay = args.weight_decay if args.weight_decay > 0 else 0.01      # AdamW default of src/train.py:321-325
     criterion = make_criterion(args.label_smoothing)
-    augment_fn = build_augment_fn(args, fused=(device.type == "cuda"))   # batches are on the GPU when it is applied
+    # batches are on the GPU when it is applied; for CNN2D the augmentation is folded into the kernels' loads
+    augment_fn = build_augment_fn(args, fused=(device.type == "cuda"), fold=(device.type == "cuda" and args.model == "cnn2d"))
     if isinstance(augment_fn, FusedAugment):
         augment_fn.seed = dfa_dist.rank_seed(augment_fn.seed, rank)
 

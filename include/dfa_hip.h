@@ -133,11 +133,20 @@ int dfa_bce_smooth_fwd_bwd(dfa_ctx* ctx, const float* logits, const float* label
  * The caller draws the per-batch parameters exactly as the reference does (Python `random` spans and shift, torch
  * generator keep mask); mask spans refer to the frames / feature dims BEFORE the shift (the reference's op order:
  * time mask, feature mask, roll, channel drop, jitter); len = 0 disables a mask, keep_f = NULL and jitter_std = 0 disable
- * the other two; the noise is the library's Philox stream keyed by (seed, offset).  Out of place; any strides. */
+ * the other two; the noise is the library's Philox stream keyed by (seed, offset + (b*T + t)*F + f).  Out of place; any strides. */
 int dfa_augment_batch(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                       int64_t stride_f, void* out, int out_dtype, int64_t out_stride_b, int64_t out_stride_t,
                       int64_t out_stride_f, int shift, const float* keep_f, int tmask_start, int tmask_len,
                       int fmask_start, int fmask_len, float jitter_std, uint64_t seed, uint64_t offset);
+/* The same augmentation FOLDED INTO THE LOADS of the training step (src/train.py:68-69 applies the
+ * augmentation to the batch and hands the result to the model): arms the parameters for the NEXT dfa_cnn2d_forward_train /
+ * dfa_cnn2d_backward pair, whose three kernels that read x (statistics pass, block 1, block-1 backward) then read
+ * keep_f[f] * mask(x[b][(t - shift) mod T][f]) + jitter_std * N(0,1) instead of x -- no augmented copy of the batch is
+ * written or re-read.  One-shot: consumed by that forward; enable = 0 disarms.  keep_f (device float[F] or NULL) must stay
+ * valid until the backward has run.  The element formula, noise stream included, is the one of dfa_augment_batch. */
+int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
+                                int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
+                                uint64_t offset);
 /* one torch.optim.AdamW step over a flat fp32 buffer: p *= 1-lr*wd; m,v update; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).
  * grad_scale multiplies the gradient first (1/world after a sum all-reduce).  step is 1-based. */
 int dfa_adamw_step(dfa_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,

@@ -62,3 +62,45 @@ def test_fused_augment_jitter_statistics_and_errors():
     assert out16.dtype == torch.bfloat16 and torch.equal(out16, a.to(torch.bfloat16))
     with pytest.raises(RuntimeError):
         aug(torch.zeros(2, 8, 8))
+
+
+def test_augmentation_folded_into_training_loads_equals_standalone_pass():
+    """FusedAugment(fold=True) arms the parameters on the context and returns the batch untouched; the CNN2D
+    train-mode forward / backward then read x through the augmentation inside the kernels that load x.  Logits, loss and
+    every gradient must be IDENTICAL (fp32, bit for bit: same element values enter the same kernels) to running the
+    stand-alone pass first -- masks, shift, channel drop AND the jitter noise field -- for both feature layouts; and the
+    armed state is one-shot."""
+    from dfa_amd.augmentation import FusedAugment
+    from dfa_amd.model import CNN2D
+    cfg = dict(spec_augment=True, time_mask_ratio=0.2, feature_mask=True, feature_mask_ratio=0.1, time_shift=True,
+               time_shift_ratio=0.1, channel_drop=True, channel_drop_prob=0.3, gaussian_jitter=True,
+               gaussian_jitter_std=0.05)
+    g = torch.Generator().manual_seed(5)
+    for layout, (B, T, F) in (("bft_view", (3, 40, 180)), ("btf", (2, 17, 65)), ("bft_view", (2, 321, 180))):
+        stored = (torch.randn(B, F, T, generator=g) if layout == "bft_view" else torch.randn(B, T, F, generator=g)) * 3.0
+        x = stored.to("cuda").transpose(1, 2) if layout == "bft_view" else stored.to("cuda")
+        y = (torch.rand(B, generator=g) > 0.5).float().to("cuda")
+        results = []
+        for fold in (False, True):
+            torch.manual_seed(9)
+            model = CNN2D(in_features=F, dropout=0.2).to("cuda").train()
+            model._drop_seed = 123
+            with torch.no_grad():
+                model.classifier.weight.mul_(30.0)
+            random.seed(31); torch.manual_seed(31)
+            aug = FusedAugment(seed=77, fold=fold, **cfg)
+            xa = aug(x)
+            if fold:
+                assert xa.data_ptr() == x.data_ptr()                       # nothing was computed or copied
+            logits = model(xa).squeeze(-1)
+            loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+            loss.backward()
+            results.append((logits.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}, model))
+        (l0, g0, _), (l1, g1, m1) = results
+        assert torch.equal(l0, l1), (layout, float((l0 - l1).abs().max()))
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (layout, n, float((g0[n] - g1[n]).abs().max()))
+        # one-shot: the next forward sees the raw batch again
+        m1.zero_grad()
+        plain = m1(x)
+        assert not torch.equal(plain.squeeze(-1), l1)
