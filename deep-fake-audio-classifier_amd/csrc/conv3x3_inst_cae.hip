@@ -36,6 +36,10 @@ hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStrea
   p2.in_ch_off_bytes = 64 * 4;
   p2.acc_in = raw_tmp;
   p2.wpack = a.wpack + (size_t)(256 / 32) * 9 * 8 * 64;
+  // train_conv_variant 7 / 8 (diagnostic, tools/gpu_accin_probe.py): the asm-pipelined forms (3 / 4 reads in flight) of this
+  // one-wave-per-SIMD fp32 ACCIN kernel with 288 weight registers; never the default
+  if (train_conv_variant() == 7) return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_POOL_2X2, 1, true, false, false, 3>(p2, s);
+  if (train_conv_variant() == 8) return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_POOL_2X2, 1, true, false, false, 4>(p2, s);
   return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_POOL_2X2, 1, true>(p2, s);
 }
 

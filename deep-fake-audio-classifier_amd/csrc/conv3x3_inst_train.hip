@@ -57,6 +57,9 @@ hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipS
   p2.in_ch_off_bytes = 64 * 4;
   p2.acc_in = raw_tmp;
   p2.wpack = a.wpack + (size_t)(64 / 32) * 9 * 8 * 64;
+  // variant 7 (diagnostic, tools/gpu_accin_probe.py): the asm-pipelined form of this one-wave-per-SIMD fp32 ACCIN kernel --
+  // the configuration whose wrong sums round 1 recorded; never the default
+  if (g_train_conv_variant == 7) return launch_conv3x3<float, 64, 2, 2, 2, 1, EPI_PLAIN, 1, true, true, false, 3>(p2, s);
   return launch_conv3x3<float, 64, 2, 2, 2, 1, EPI_PLAIN, 1, true, true>(p2, s);
 }
 

@@ -207,12 +207,24 @@ def test_pipelined_lds_reads_are_never_touched_in_flight():
         pytest.skip("hipcc not available")
     csrc = os.path.join(root, "deep-fake-audio-classifier_amd", "csrc")
     total = 0
+    known = "conv3x3_mfma_kernelIfLi64ELi4ELi1ELi1ELi1ELi1ELi1ELb1ELb0ELb0ELi3E"   # the diagnostic instantiation (variant 7)
+    flagged_known, nmfma = 0, 0
     for name in ("conv3x3_inst_cnn2d.hip", "conv3x3_inst_cae.hip", "conv12_fused.hip", "conv3_m16.hip", "wgrad_mfma.hip",
                  "conv3x3_inst_train.hip", "conv_split.hip"):
-        kernels, nreads, violations = chk.check_asm(chk.compile_to_asm(os.path.join(csrc, name)))
+        asm = chk.compile_to_asm(os.path.join(csrc, name))
+        kernels, nreads, violations = chk.check_asm(asm)
         assert not violations, violations[:5]
         total += nreads
+        # second rule: a weight fragment half-reassembled across loop phases (the hipcc miscompile behind round 1's "wrong
+        # sums" of the pipelined fp32 ACCIN kernel).  It must flag the diagnostic instantiation kept for that purpose -- the
+        # positive control, confirmed wrong on the GPU by tools/gpu_accin_probe.py -- and nothing that ships.
+        nk, nm, v2 = chk.check_operand_provenance(asm)
+        nmfma += nm
+        flagged_known += sum(1 for k, _, _ in v2 if known in k)
+        others = [v for v in v2 if known not in v[0]]
+        assert not others, others[:5]
     assert total > 0          # the pipelined instantiations exist
+    assert nmfma > 10000 and flagged_known >= 1
 
 
 def test_m16_swizzle_is_conflict_free():

@@ -7,6 +7,19 @@ v_mov ...) before the wait, it moves stale data.  This script compiles a .hip fi
 kernel, that no instruction touches the destination of an in-flight asm read before a wait has retired it, and that
 no asm read is in flight across a loop back-edge (forward skips are covered by the linear scan).
 
+Second rule (round 2): MATRIX-OPERAND PROVENANCE.  The wrong sums round 1 recorded for the pipelined one-wave-per-SIMD fp32
+ACCIN kernel were traced (tools/gpu_accin_probe2.py + the ISA) to a register-allocation miscompile of hipcc (ROCm 7.2), not
+to the pipeline: with all 512 registers in use and weights shuttling through scratch and AGPRs, the 128-bit weight fragment
+w[tap 0][k-group 0] was split into {scratch slot (x, y), a141 (z), a140 (w)}; phase 0 of the three-way unrolled walk
+reassembles it correctly, phases 1 and 2 reload (x, y), copy w -- and never copy z: their first MFMAs read an accumulator
+register that still holds element z of ANOTHER fragment, written by phase 0.  The in-flight rule cannot see that (no LDS
+destination is touched).  What makes it visible statically: the MFMAs that consume the 2 or 4 elements of one LDS fragment
+(consecutive registers of one asm read, same accumulator) take the matching elements of ONE weight fragment as their other
+operand.  Inside the main loop each of those weight registers is either loop-invariant (never written in the loop), or
+written earlier in the same barrier-delimited phase (reloaded / copied), or carried over from another phase (a reload the
+compiler hoisted).  A fragment group that MIXES "written in this phase" with "carried over from another phase" is a
+half-reassembled fragment -- exactly the miscompile above -- and is reported.
+
 usage: check_lds_pipeline.py file.hip [more.hip ...]      (exit code 1 on a violation)
 """
 import os
@@ -96,11 +109,118 @@ def check_asm(text):
     return kernels, nreads, violations
 
 
+AREG = re.compile(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b")
+
+
+def _regs(tok):
+    out = set()
+    for m in AREG.finditer(tok):
+        if m.group(4) is not None:
+            out.add((m.group(4), int(m.group(5))))
+        else:
+            out.update((m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check_operand_provenance(text):
+    """returns (kernels with a main loop, MFMAs checked, violations): see the module docstring, second rule."""
+    violations, nk, nm = [], 0, 0
+    lines = text.split("\n")
+    starts = [i for i, l in enumerate(lines) if l.startswith("_Z") and l.rstrip().split(";")[0].rstrip().endswith(":")]
+    for st in starts:
+        try:
+            en = next(i for i in range(st, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+        except StopIteration:
+            continue
+        body = [l.split(";")[0].strip() if not l.strip().startswith(";;#") else "" for l in lines[st:en]]
+        label_at = {l[:-1]: i for i, l in enumerate(body) if l.endswith(":") and not l.startswith("_Z")}
+        # outermost loop that contains MFMAs: widest backward branch span
+        loop = None
+        for i, l in enumerate(body):
+            if l.startswith(("s_cbranch", "s_branch")):
+                tgt = l.split()[-1]
+                j = label_at.get(tgt)
+                if j is not None and j < i and any(b.startswith("v_mfma") for b in body[j:i]):
+                    if loop is None or (i - j) > (loop[1] - loop[0]):
+                        loop = (j, i)
+        if loop is None:
+            continue
+        nk += 1
+        lo, hi = loop
+        bars = [i for i in range(lo, hi + 1) if body[i].startswith("s_barrier")]
+        bounds = [lo] + bars + [hi + 1]
+        seg_of = {}
+        for k in range(len(bounds) - 1):
+            for i in range(bounds[k], bounds[k + 1]):
+                seg_of[i] = k
+        written = {}                       # reg -> set of segments where it is written inside the loop
+        writes_before = {}                 # (segment, reg) -> first line of a write
+        for i in range(lo, hi + 1):
+            l = body[i]
+            if not l or l.endswith(":") or l.startswith(("s_", ";", ".")):
+                continue
+            toks = l.split(None, 1)
+            if len(toks) < 2:
+                continue
+            if toks[0].startswith(("global_store", "scratch_store", "ds_write", "buffer_store", "global_atomic")):
+                continue
+            for r in _regs(toks[1].split(",")[0]):
+                written.setdefault(r, set()).add(seg_of[i])
+                writes_before.setdefault((seg_of[i], r), i)
+        # asm-read destination tuples (fragments) by register
+        frag_of = {}
+        for i in range(lo, hi + 1):
+            if body[i].startswith("ds_read_b128") or body[i].startswith("ds_read_b64"):
+                dst = sorted(_regs(body[i].split(None, 1)[1].split(",")[0]))
+                for r in dst:
+                    frag_of[r] = dst[0]
+        groups = {}                        # (segment, accumulator, fragment base, ordinal of that fragment's reuse) -> statuses
+        seen = {}
+        for i in range(lo, hi + 1):
+            l = body[i]
+            if l.startswith("ds_read"):
+                for r in _regs(l.split(None, 1)[1].split(",")[0]):
+                    seen[frag_of.get(r, r)] = seen.get(frag_of.get(r, r), 0) + 1
+                continue
+            if not l.startswith("v_mfma"):
+                continue
+            ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
+            nm += 1
+            ra, rb = sorted(_regs(ops[1])), sorted(_regs(ops[2]))
+            # which operand is the LDS fragment?  (weights are the A operand in conv3x3_mfma / conv_split, B in wgrad)
+            fa, fb = [r for r in ra if r in frag_of], [r for r in rb if r in frag_of]
+            frag, other = (fb, ra) if fb else (fa, rb)
+            if not frag:
+                continue
+            key = (seg_of[i], ops[0], frag_of[frag[0]], seen.get(frag_of[frag[0]], 0))
+            for r in other:
+                segs = written.get(r)
+                if not segs:
+                    st_ = "invariant"
+                else:
+                    w = writes_before.get((seg_of[i], r))
+                    st_ = "phase" if (w is not None and w < i) else "carried"
+                groups.setdefault(key, []).append((st_, r, i, l))
+        for key, items in groups.items():
+            kinds = {k for k, _, _, _ in items}
+            if "phase" in kinds and "carried" in kinds:
+                for k, r, i, l in items:
+                    if k == "carried":
+                        violations.append((lines[st].split(":")[0], st + i + 1,
+                                           f"weight register {r[0]}{r[1]} is carried over from another loop phase while the rest of its "
+                                           f"fragment was rewritten in this phase: {l}"))
+    return nk, nm, violations
+
+
 def main(paths):
     bad = 0
     for p in paths:
-        kernels, nreads, violations = check_asm(compile_to_asm(p))
-        print(f"{os.path.basename(p)}: {kernels} kernels, {nreads} pipelined LDS reads, {len(violations)} violations")
+        asm = compile_to_asm(p)
+        kernels, nreads, violations = check_asm(asm)
+        nk, nm, v2 = check_operand_provenance(asm)
+        violations = violations + v2
+        print(f"{os.path.basename(p)}: {kernels} kernels, {nreads} pipelined LDS reads, {nm} loop MFMAs in {nk} kernels, "
+              f"{len(violations)} violations")
         for k, ln, msg in violations[:20]:
             print(f"  {k[:90]} line {ln}: {msg}")
         bad += len(violations)
