@@ -117,12 +117,25 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   const TX* xb = (const TX*)a.x + (long long)b * a.sxb;
   unsigned short xreg[NXLD];   // raw loaded bits; out-of-image elements are zeroed when they are stored, not here: a
   bool xok[NXLD];              // select on the loaded value would make the wave wait out the load latency at issue time
+  // per-thread constants of the feature loads: the element's offset for ring block 0 and whether its column exists; a ring
+  // block only adds the wave-uniform 8*j*sxt (no 64-bit multiplies in the loop)
+  long long xoff[NXLD];
+  bool xfok[NXLD];
+#pragma unroll
+  for (int k = 0; k < NXLD; ++k) {
+    const int f = f0 - 2 + xcol[k];
+    xfok[k] = (k * 256 + tid < NX) && f >= 0 && f < W;
+    xoff[k] = (long long)(xrow[k] - 3) * a.sxt + (long long)(xfok[k] ? f : 0) * a.sxf;
+  }
   auto x_load = [&](int j) {
+    const long long jo = (long long)(8 * j) * a.sxt;        // wave-uniform
 #pragma unroll
     for (int k = 0; k < NXLD; ++k) {
-      const int t = 8 * j - 3 + xrow[k], f = f0 - 2 + xcol[k];
-      xok[k] = (k * 256 + tid < NX) && t >= 0 && t < T && f >= 0 && f < W;
-      xreg[k] = cvt_out<bf16_t>(ld_as_float(xb + (xok[k] ? (long long)t * a.sxt + (long long)f * a.sxf : 0))).v;   // clamped address, branch-free
+      const int t = 8 * j - 3 + xrow[k];
+      xok[k] = xfok[k] && (unsigned)t < (unsigned)T;
+      const TX* src = xb + (xok[k] ? xoff[k] + jo : 0);     // clamped address, branch-free
+      if constexpr (sizeof(TX) == 2) xreg[k] = *(const unsigned short*)src;            // bf16 features: the bits as they are
+      else xreg[k] = cvt_out<bf16_t>(ld_as_float(src)).v;                               // fp32 features: RNE on load
     }
   };
   auto x_store = [&](int buf) {   // element (row, c) is tap e of the windows of slots c - e, e = 0..2
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   const int col = f0 + r;
   const bool col_ok = (r < SW) && col < W;
   const int niter = (H + BR - 1) / BR;
+  bf16_t* const obase = a.out + ((size_t)b * (H >> 1) * W + (col_ok ? col : 0)) * 64 + nb + 8 * h;   // + to * W * 64 per unit
 
 #ifdef DFA_STAMPS   // diagnostic build (make stamps): per-wave cycle split, printed by the launcher
   long long seg[6] = {0, 0, 0, 0, 0, 0};
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = acc0[i] + relu1(acc1[i], rlim);
-    bf16_t* o = a.out + (((size_t)b * Ho + to) * W + col) * 64 + nb;
+    bf16_t* o = obase + (size_t)to * (W * 64);
     const bool ok = (to < Ho) && col_ok;
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
       const unsigned b0 = pack_bf16x2(v[4 * g + 4], v[4 * g + 5]), b1 = pack_bf16x2(v[4 * g + 6], v[4 * g + 7]);
       const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-      if (ok) *(uint4*)(o + 8 * g + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      if (ok) *(uint4*)(o + 8 * g) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
     }
   };
 

@@ -1,0 +1,51 @@
+"""Build profiles/rNN_pmc_traffic.json from the per-counter CSVs that tools/rocpd_summary.py (pmc) or rocprofv3's own
+counter_collection CSV produce.  usage: pmc_traffic_json.py <out.json> <tag>=<counter_collection.csv> ...
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE (KB, 64-B requests tallied for 128-B ones) is doubled;
+WRITE_SIZE (KB) is exact; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (mean over the launches seen)."""
+import csv, json, sys, collections
+
+
+def read_counter_csv(path):
+    """rocprofv3 --output-format csv counter_collection: columns Kernel_Name, Counter_Name, Counter_Value (one row per dispatch)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+ALGO = {   # algorithmic bytes per launch at B = 256, T = 321, F = 180
+    "conv12_fused_kernel": 256 * (321 * 180 * 2 + 80 * 180 * 64 * 2),
+    "conv3_m16_meant_kernel": 256 * (80 * 180 * 64 * 2 + 128 * 180 * 4),
+    "conv_split_kernel<32": 256 * (160 * 180 * 32 * 4 + 80 * 180 * 64 * 4),
+    "conv_split_kernel<64": 256 * (80 * 180 * 64 * 4 + 128 * 180 * 4),
+    "conv_split_kernel<128": 256 * (80 * 180 * 128 * 2 + 80 * 180 * 64 * 2),
+    "conv1_bn_relu_poolh2_kernel": 256 * (321 * 180 * 4 + 160 * 180 * 32 * 4),
+}
+
+if __name__ == "__main__":
+    out, merged = sys.argv[1], collections.defaultdict(dict)
+    for spec in sys.argv[2:]:
+        tag, path = spec.split("=", 1)
+        for kern, counters in read_counter_csv(path).items():
+            for c, vals in counters.items():
+                merged[kern][c] = sum(vals) / len(vals)
+                merged[kern][c + "_launches"] = len(vals)
+    blob = {"source": "rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3 tools/gpu_prof_fwd.py / gpu_prof_train.py "
+                      "(B=256, T=321, F=180); per-kernel means over the launches of each pass",
+            "correction": "gfx950: FETCH_SIZE (KB) under-reports wide streaming reads by exactly 2x (MI355X_MICROARCH.md, HBM); "
+                          "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "kernels": {}}
+    for kern, c in sorted(merged.items()):
+        if not kern.startswith(("dfa::", "void dfa::")):
+            continue
+        rec = {k: round(v, 1) for k, v in c.items()}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            rec["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        for key, nbytes in ALGO.items():
+            if key in kern:
+                rec["algorithmic_bytes_per_launch"] = nbytes
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
+            rec["note_mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs"
+        blob["kernels"][kern] = rec
+    json.dump(blob, open(out, "w"), indent=1)
+    print("wrote", out, len(blob["kernels"]), "kernels")
