@@ -44,24 +44,20 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
 
 
 def pmc_traffic(prec):
-    """HBM bytes per launch of the block-3 kernel from the committed rocprofv3 PMC passes of this bench command
-    (profiles/r02_pmc_traffic.json, made by tools/rocpd_summary.py from separate --pmc runs; hardware counters cannot be
-    read from inside this process).  None if the summary is absent."""
-    try:
-        blob = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            path = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(path):
-                blob = json.load(open(path))
-                break
-        if blob is None:
-            return None
-    except (OSError, ValueError):
-        return None
-    tag = {"bf16": "conv3_m16_meant_kernel", "fp32": "conv3x3_mfma_kernel<float, 64, 4", "bf16x3": "conv_split_kernel<64"}[prec]
-    for name, rec in blob.get("kernels", {}).items():
-        if tag in name:
-            return rec.get("hbm_bytes_per_launch")
+    """HBM bytes per launch of the block-3 kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json for
+    the bf16 / bf16x3 kernels at HEAD, made by tools/pmc_traffic_json.py from separate --pmc runs of tools/gpu_prof_fwd.py;
+    the fp32 kernel is unchanged since round 1 and keeps profiles/r01_pmc_traffic.json).  Hardware counters cannot be read
+    from inside this process.  None if no summary holds the kernel."""
+    tag = {"bf16": "conv3_m16_meant_kernel<true, false>", "fp32": "conv3x3_mfma_kernel<float, 64, 4",
+           "bf16x3": "conv_split_kernel<64, 8, 1"}[prec]
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            blob = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        for kname, rec in blob.get("kernels", {}).items():
+            if tag in kname and rec.get("hbm_bytes_per_launch"):
+                return rec["hbm_bytes_per_launch"]
     return None
 
 

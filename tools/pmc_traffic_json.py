@@ -17,9 +17,11 @@ def read_counter_csv(path):
 ALGO = {   # algorithmic bytes per launch at B = 256, T = 321, F = 180
     "conv12_fused_kernel": 256 * (321 * 180 * 2 + 80 * 180 * 64 * 2),
     "conv3_m16_meant_kernel": 256 * (80 * 180 * 64 * 2 + 128 * 180 * 4),
-    "conv_split_kernel<32": 256 * (160 * 180 * 32 * 4 + 80 * 180 * 64 * 4),
-    "conv_split_kernel<64": 256 * (80 * 180 * 64 * 4 + 128 * 180 * 4),
-    "conv_split_kernel<128": 256 * (80 * 180 * 128 * 2 + 80 * 180 * 64 * 2),
+    "conv_split_kernel<32, 4, 0": 256 * (160 * 180 * 32 * 4 + 80 * 180 * 64 * 4),     # bf16x3 block 2: a1 split in, a2 split out
+    "conv_split_kernel<64, 8, 1": 256 * (80 * 180 * 64 * 4 + 128 * 180 * 4),          # bf16x3 block 3: a2 split in, embedding out
+    "conv_split_kernel<128, 4, 2": 256 * (80 * 180 * 128 * 2 + 80 * 180 * 64 * 2),    # train: dz3 in, da2 out
+    "conv_split_kernel<64, 2, 2": 256 * (160 * 180 * 64 * 2 + 160 * 180 * 32 * 2),    # train: dz2 in, da1 out
+    "conv3_m16_meant_kernel<true, true>": 256 * (80 * 180 * 64 * 2 + 80 * 180 * 128 * 2),   # train forward 3: a2 in, z3 out
     "conv1_bn_relu_poolh2_kernel": 256 * (321 * 180 * 4 + 160 * 180 * 32 * 4),
 }
 
@@ -41,11 +43,15 @@ if __name__ == "__main__":
         rec = {k: round(v, 1) for k, v in c.items()}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             rec["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
-        for key, nbytes in ALGO.items():
-            if key in kern:
-                rec["algorithmic_bytes_per_launch"] = nbytes
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
-            rec["note_mfma"] = "SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs"
+        for key, nbytes in ALGO.items():         # the most specific (longest) matching key wins
+            if key in kern and len(key) >= len(rec.get("_k", "")):
+                rec["algorithmic_bytes_per_launch"], rec["_k"] = nbytes, key
+        rec.pop("_k", None)
+        if "hbm_bytes_per_launch" in rec and "algorithmic_bytes_per_launch" in rec:
+            rec["hbm_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"], 3)
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs issue MFMAs
+            rec["mfma_busy_fraction"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 3)
         blob["kernels"][kern] = rec
     json.dump(blob, open(out, "w"), indent=1)
     print("wrote", out, len(blob["kernels"]), "kernels")
