@@ -169,25 +169,36 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     });
     if constexpr (TRAIN) {
       const bool r0 = t0 < H, r1 = t0 + 1 < H;                    // wave-uniform
+      // statistics of the fp32 accumulators (as the 32x32x16 kernel); rows / columns outside the image do not count
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb) {
-        const int col = f0 + 16 * pb + p;
-        const bool cok = col < W;
-        bf16_t* z0 = (bf16_t*)a.out + (((size_t)b * H + t0) * W + col) * COUT + cout_base + nsl * 32 + 4 * q;
-        bf16_t* z1 = z0 + (size_t)W * COUT;
+        const bool cok = f0 + 16 * pb + p < W;
 #pragma unroll
         for (int ca = 0; ca < 2; ++ca) {
-          // statistics of the fp32 accumulators (as the 32x32x16 kernel); rows / columns outside the image do not count
           if (cok && r0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { cs[0][ca][e] += acc0[ca][pb][e]; cs[1][ca][e] = fmaf(acc0[ca][pb][e], acc0[ca][pb][e], cs[1][ca][e]); }
-            *(uint2*)(z0 + 16 * ca) = make_uint2(pack_bf16x2(acc0[ca][pb][0], acc0[ca][pb][1]), pack_bf16x2(acc0[ca][pb][2], acc0[ca][pb][3]));
           }
           if (cok && r1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { cs[0][ca][e] += acc1[ca][pb][e]; cs[1][ca][e] = fmaf(acc1[ca][pb][e], acc1[ca][pb][e], cs[1][ca][e]); }
-            *(uint2*)(z1 + 16 * ca) = make_uint2(pack_bf16x2(acc1[ca][pb][0], acc1[ca][pb][1]), pack_bf16x2(acc1[ca][pb][2], acc1[ca][pb][3]));
           }
+        }
+      }
+      // z stores: v_permlane16_swap between the two pixel tiles hands every lane 8 consecutive channels of ONE pixel --
+      // quarter-wave rows q = 0 / 2 keep tile 0 (channels 8*(q/2) .. +7 of the 16-channel tile), rows 1 / 3 take tile 1 --
+      // so z leaves as 16-byte stores (4 per lane and unit instead of 8 of 8 bytes)
+      const int tile = q & 1;
+      const int col = f0 + 16 * tile + p;
+      bf16_t* zb = (bf16_t*)a.out + (((size_t)b * H + t0) * W + col) * COUT + cout_base + nsl * 32 + 8 * (q >> 1);
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const f32x4_t v0 = r ? acc1[ca][0] : acc0[ca][0], v1 = r ? acc1[ca][1] : acc0[ca][1];
+          const auto d0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+          const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+          if (col < W && (r ? r1 : r0)) *(uint4*)(zb + (size_t)r * W * COUT + 16 * ca) = make_uint4(d0[0], d1[0], d0[1], d1[1]);
         }
       }
     } else
