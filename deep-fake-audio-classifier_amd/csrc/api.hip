@@ -12,6 +12,8 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int kMaxSeg = 8;
+
 struct Cnn2dPlan {
   int H1, H2;               // rows after pool 1 / pool 2
   size_t a1_off, a2_off, emb_off, total;
@@ -28,9 +30,28 @@ Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
   p.a2_off = off;
   off = align_up(off + (size_t)B * p.H2 * F * 64 * es, 256);
   p.emb_off = off;
-  off = align_up(off + (size_t)B * 128 * F * sizeof(float), 256);
+  // small batches split the time axis over up to kMaxSeg workgroups per strip: one partial embedding per segment
+  const int nstrips = (F + 31) / 32;
+  const size_t nemb = ((size_t)B * nstrips < 512) ? kMaxSeg : 1;
+  off = align_up(off + nemb * (size_t)B * 128 * F * sizeof(float), 256);
   p.total = off;
   return p;
+}
+
+// iterations per time-axis segment for a kernel that walks `niter` iterations with `nwg` workgroups and `slots` resident
+// workgroup slots on the chip: 0 = do not split.  A multiple of `period` (ring / window-buffer phase of the kernel).
+int seg_iters_for(int niter, int nwg, int slots, int period, int forced) {
+  if (forced == 0 || niter <= period) return 0;
+  int seg;
+  if (forced > 0) seg = (niter + forced - 1) / forced;
+  else {
+    if (nwg >= slots) return 0;
+    seg = (int)(((long long)niter * nwg + slots - 1) / slots);
+  }
+  seg = (seg + period - 1) / period * period;
+  if (seg >= niter) return 0;
+  if ((niter + seg - 1) / seg > kMaxSeg) seg = ((niter + kMaxSeg - 1) / kMaxSeg + period - 1) / period * period;
+  return seg >= niter ? 0 : seg;
 }
 
 struct Cnn1dPlan {
@@ -151,6 +172,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return DFA_E_NULL_PTR;
   if (strcmp(name, "train_conv_variant") == 0) { set_train_conv_variant(value); return DFA_OK; }
   if (strcmp(name, "wgrad_variant") == 0) { set_wgrad_variant(value); return DFA_OK; }
+  if (strcmp(name, "time_split") == 0) { ctx->time_split = value; return DFA_OK; }
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
@@ -283,14 +305,21 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   void* a1 = ws + pl.a1_off;
   void* a2 = ws + pl.a2_off;
   float* emb = embedding ? embedding : (float*)(ws + pl.emb_off);
+  int nseg3 = 1;
   hipStream_t s = ctx->stream;
   // bf16 mode: blocks 1 and 2 run as one kernel and a1 stays on chip (timing slot 1); fp32 features are rounded to bf16
   // as the kernel loads them (bf16 storage mode), exactly like a caller-side .to(bfloat16)
   const bool fused12 = prec == DFA_PREC_BF16 && ctx->fuse_conv1;
+  // Small batches (B * strips below the chip's resident-workgroup count; the reference's predict.py default is batch 32):
+  // every workgroup would walk the whole time axis alone, so the axis is split into segments that separate workgroups walk
+  // (blocks 1+2: disjoint output rows; block 3: partial means per segment, added up by the classifier kernel).
+  const int nstrips32 = (F + 31) / 32;
   if (fused12) {
     ScopedSlot ts(ctx, 1);
+    const int nstrips30 = (F + 29) / 30;
+    const int seg12 = seg_iters_for((pl.H1 + 3) / 4, B * nstrips30, 512, 6, ctx->time_split);
     DFA_HIP_CHECK(ctx, launch_conv12_fused(x, x_dtype, stride_b, stride_t, stride_f, m.c1pack, m.c1bias, m.c2.wpack, m.c2.bias, a2,
-                                           B, T, F, s, ctx->lds_pipe));
+                                           B, T, F, s, ctx->lds_pipe, seg12));
   } else {
     ScopedSlot ts(ctx, 0);
     DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.w1, m.b1, a1, prec, B, T, F, s));
@@ -300,6 +329,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ConvArgs a{};
     a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;
     a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1; a.zero_page = ctx->zero_page;
+    if (prec == DFA_PREC_BF16X3) a.seg_iters = seg_iters_for((pl.H1 + 1) / 2, B * nstrips32, 768, 3, ctx->time_split);
     if (prec == DFA_PREC_BF16X3) DFA_HIP_CHECK(ctx, launch_cnn2d_block2_split(a, s, ctx->lds_pipe));
     else DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
   }
@@ -308,6 +338,20 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ConvArgs a{};
     a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
+    const int niter3 = (pl.H2 + 1) / 2;
+    const int chunk3 = 6 * std::max(1, (niter3 + 6 * kMaxSeg - 1) / (6 * kMaxSeg));   // canonical chunks: depends on T only, <= kMaxSeg of them
+    if (prec == DFA_PREC_BF16X3) {
+      a.chunk_iters = chunk3;
+      a.seg_iters = seg_iters_for(niter3, B * nstrips32, 256, chunk3, ctx->time_split);
+    } else if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
+      a.chunk_iters = chunk3;
+      a.seg_iters = seg_iters_for(niter3, B * nstrips32, 512, chunk3, ctx->time_split);
+    }
+    if (a.seg_iters) {           // one slab of (unscaled) sums per canonical chunk in the workspace; the classifier kernel adds them
+      nseg3 = (niter3 + chunk3 - 1) / chunk3;
+      a.emb = (float*)(ws + pl.emb_off);
+      a.emb_seg_stride = (size_t)B * 128 * F;
+    }
     if (prec == DFA_PREC_BF16X3) {
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3_split(a, s, ctx->lds_pipe));
     } else if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
@@ -319,7 +363,11 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   }
   {
     ScopedSlot ts(ctx, 3);
-    DFA_HIP_CHECK(ctx, launch_linear(emb, m.p[18], m.p[19], logits, B, 128 * F, s));
+    if (nseg3 > 1)
+      DFA_HIP_CHECK(ctx, launch_linear((const float*)(ws + pl.emb_off), m.p[18], m.p[19], logits, B, 128 * F, s, nseg3,
+                                       (size_t)B * 128 * F, embedding, 1.0f / (float)pl.H2));
+    else
+      DFA_HIP_CHECK(ctx, launch_linear(emb, m.p[18], m.p[19], logits, B, 128 * F, s));
   }
   return DFA_OK;
 }

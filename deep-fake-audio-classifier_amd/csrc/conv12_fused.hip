@@ -34,6 +34,7 @@ struct Conv12Args {
   const float* bias;        // [64]
   bf16_t* out;              // a2 [B][H1/2][F][64]
   int B, T, F, H1, nstrips;
+  int seg_iters;            // time-axis split for small batches: blockIdx.y walks seg_iters iterations (multiple of 6), 0 = all
 };
 
 __device__ __forceinline__ float ld_as_float(const float* p) { return *p; }
@@ -220,15 +221,19 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
 #else
   auto stamp = [&](int) {};
 #endif
-  // ---- prologue: windows of blocks 0, 1 -> ring blocks 0, 1; windows of block 2
+  // small batches: blockIdx.y walks its own segment [it0, niter) of the time axis.  it0 is a multiple of 6: of the ring
+  // period 3 (ring block j lives in slot j % 3) and of the window-buffer period 2 (windows of block j in buffer j & 1)
+  const int it0 = a.seg_iters ? (int)blockIdx.y * a.seg_iters : 0;
+  const int niter_seg = a.seg_iters ? min(niter, it0 + a.seg_iters) : niter;
+  // ---- prologue: windows of blocks it0, it0+1 -> ring blocks 0, 1; windows of block it0+2
   __syncthreads();                 // window pads / bias written
-  x_load(0); x_store(0);
-  x_load(1); x_store(1);
+  x_load(it0); x_store(0);
+  x_load(it0 + 1); x_store(1);
   __syncthreads();
-  produce_now(0, 0);
-  produce_now(1, 1);
+  produce_now(it0, 0);
+  produce_now(it0 + 1, 1);
   __syncthreads();
-  x_load(2); x_store(0);
+  x_load(it0 + 2); x_store(0);
   __syncthreads();
 
   // ---- block 2 unit (conv3x3_mfma.h, <bf16, CIN 32, POOL_H2>, asm-pipelined fragment reads) + the block-1 tile of
@@ -314,10 +319,10 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     stamp(3);
   };
   stamp(5);
-  for (int it = 0; it < niter; it += 3) {
+  for (int it = it0; it < niter_seg; it += 3) {
     iteration(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
-    if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
+    if (it + 1 < niter_seg) iteration(std::integral_constant<int, 1>{}, it + 1);
+    if (it + 2 < niter_seg) iteration(std::integral_constant<int, 2>{}, it + 2);
   }
 #ifdef DFA_STAMPS
   if (lane == 0 && blockIdx.x < 2048) {
@@ -364,14 +369,17 @@ static hipError_t launch_conv12_t(const Conv12Args& a, int B, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * a.nstrips), dim3(256), c12::LDS_BYTES, s, a);
+  const int niter = (a.H1 + c12::BR - 1) / c12::BR;
+  const int nseg = a.seg_iters ? (niter + a.seg_iters - 1) / a.seg_iters : 1;
+  hipLaunchKernelGGL(kern, dim3(B * a.nstrips, nseg), dim3(256), c12::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack,
                                const float* c1bias, const uint4* wpack2, const float* bias2, void* a2, int B, int T,
-                               int F, hipStream_t s, int pipe) {
+                               int F, hipStream_t s, int pipe, int seg_iters) {
   Conv12Args a{};
+  a.seg_iters = seg_iters;
   a.x = x; a.sxb = sb; a.sxt = st; a.sxf = sf;
   a.c1pack = c1pack; a.c1bias = c1bias; a.wpack = wpack2; a.bias = bias2; a.out = (bf16_t*)a2;
   a.B = B; a.T = T; a.F = F; a.H1 = T / 2; a.nstrips = (F + c12::SW - 1) / c12::SW;

@@ -23,7 +23,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 namespace m16 {
 constexpr int PB = 128, CPP = 8, SP = 36, ROWB = SP * PB, BR = 2, NSL = 4, NT = 256;
 constexpr int NCH = BR * SP * CPP, NLD = (NCH + NT - 1) / NT;
-constexpr int RING_BYTES = 3 * BR * ROWB, BIAS_BYTES = NSL * 32 * 4, LDS_BYTES = RING_BYTES + BIAS_BYTES;
+constexpr int RING_BYTES = 3 * BR * ROWB, BIAS_BYTES = NSL * 32 * 4, TOT_BYTES = NT * 64;   // running time-mean total: 16 floats per lane
+constexpr int LDS_BYTES = RING_BYTES + BIAS_BYTES + TOT_BYTES;
 __device__ __forceinline__ int swz(int slot) { return slot & 6; }
 }  // namespace m16
 
@@ -112,9 +113,12 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) cs[ca][pb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int niter = (H + BR - 1) / BR;
-  stage_dma(0, 0);
-  stage_dma(1, 1);
+  const int niter_all = (H + BR - 1) / BR;
+  // small batches: blockIdx.z walks its own segment [it0, niter) of the time axis (it0 a multiple of the ring period)
+  const int it0 = a.seg_iters ? (int)blockIdx.z * a.seg_iters : 0;
+  const int niter = a.seg_iters ? min(niter_all, it0 + a.seg_iters) : niter_all;
+  stage_dma(it0, 0);
+  stage_dma(it0 + 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -226,10 +230,44 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  for (int it = 0; it < niter; it += 3) {
+  f32x4_t* const tot = (f32x4_t*)(smem + RING_BYTES + BIAS_BYTES) + tid * 4;   // eval: total over the canonical chunks
+  if constexpr (!TRAIN) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tot[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const int chunk = a.chunk_iters > 0 ? a.chunk_iters : niter_all + 3;
+  for (int it = it0; it < niter; it += 3) {
     iteration(std::integral_constant<int, 0>{}, it);
     if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
     if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
+    if constexpr (!TRAIN) {
+      const int done = it + 3;
+      if (done % chunk == 0 || done >= niter) {          // wave-uniform: a canonical chunk of the time mean is complete
+        if (a.seg_iters) {                                 // split: the chunk sum (unscaled) goes to its own slab
+          float* e0 = a.emb + (size_t)(it / chunk) * a.emb_seg_stride;
+#pragma unroll
+          for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+              const int col = f0 + 16 * pb + p;
+              if (col < W) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  e0[((size_t)b * COUT + cout_base + nsl * 32 + 16 * ca + 4 * q + e) * W + col] = cs[ca][pb][e];
+              }
+            }
+        } else {
+#pragma unroll
+          for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) tot[ca * 2 + pb] += cs[ca][pb];
+        }
+#pragma unroll
+        for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) cs[ca][pb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
 
   if constexpr (TRAIN) {
@@ -257,17 +295,19 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     }
     return;
   }
+  if (a.seg_iters) return;       // split: the chunk sums are out; the classifier kernel adds and scales them
   // embedding rows [b][channel][col]: 16 consecutive columns per (channel, quarter-wave)
 #pragma unroll
   for (int ca = 0; ca < 2; ++ca)
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
+      const f32x4_t tv = tot[ca * 2 + pb];
       if (col < W) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = cout_base + nsl * 32 + 16 * ca + 4 * q + e;
-          a.emb[((size_t)b * COUT + c) * W + col] = cs[ca][pb][e] * a.inv_h;
+          a.emb[((size_t)b * COUT + c) * W + col] = tv[e] * a.inv_h;
         }
       }
     }
@@ -315,7 +355,8 @@ static hipError_t launch_m16_t(const ConvArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, a.COUT / 128, 1), dim3(256), m16::LDS_BYTES, stream, a);
+  const int nseg = a.seg_iters ? ((a.H + m16::BR - 1) / m16::BR + a.seg_iters - 1) / a.seg_iters : 1;
+  hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, a.COUT / 128, nseg), dim3(256), m16::LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

@@ -109,6 +109,13 @@ struct ConvArgs {
   // per output channel, partial[(blockIdx.x * COUT + channel) * 2 + {0,1}]; reduced in a fixed order by bn_finalize.
   float* stats_partial;
   const void* zero_page;  // DMA staging: >= 16 zero bytes in device memory (source of out-of-image chunks)
+  // time-axis split for small batches (conv3_m16.hip, conv_split.hip): blockIdx.z = segment, a segment walks seg_iters
+  // iterations (0 = the whole axis).  The time mean is ALWAYS summed in canonical chunks of chunk_iters iterations (a
+  // multiple of 6 that depends on H only), the chunk sums added in chunk order: an unsplit workgroup keeps the running total
+  // in LDS, a split one writes every chunk sum (unscaled) to emb + chunk * emb_seg_stride floats and the classifier kernel
+  // adds them in the same order -- so logits do not depend on the batch size or on the split, bit for bit.
+  int seg_iters, chunk_iters;
+  size_t emb_seg_stride;
 };
 
 // chunk swizzle as a function of the pixel slot (column) only

@@ -120,9 +120,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   f32x4_t cs[2];        // MEAN_T: running column sums per pixel tile
   cs[0] = cs[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int niter = (H + BR - 1) / BR;
-  stage_dma(0, 0);
-  stage_dma(1, 1);
+  const int niter_all = (H + BR - 1) / BR;
+  const int it0 = a.seg_iters ? (int)blockIdx.z * a.seg_iters : 0;     // time-axis split for small batches (ConvArgs)
+  const int niter = a.seg_iters ? min(niter_all, it0 + a.seg_iters) : niter_all;
+  stage_dma(it0, 0);
+  stage_dma(it0 + 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -237,22 +239,48 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  for (int it = 0; it < niter; it += 3) {
+  // MEAN_T: running total over the canonical chunks of the time mean (ConvArgs::chunk_iters), 8 floats per lane in LDS
+  f32x4_t* const tot = (f32x4_t*)(smem + C::RING_BYTES + COUT * 4) + tid * 2;
+  if constexpr (EPI == SPLIT_EPI_MEAN_T) tot[0] = tot[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int chunk = a.chunk_iters > 0 ? a.chunk_iters : niter_all + 3;
+  for (int it = it0; it < niter; it += 3) {
     iteration(std::integral_constant<int, 0>{}, it);
     if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
     if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
+    if constexpr (EPI == SPLIT_EPI_MEAN_T) {
+      const int done = it + 3;
+      if (done % chunk == 0 || done >= niter) {          // wave-uniform: a canonical chunk is complete
+        if (a.seg_iters) {
+          float* e0 = a.emb + (size_t)(it / chunk) * a.emb_seg_stride;
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int col = f0 + 16 * pb + p;
+            if (col < W) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) e0[((size_t)b * COUT + 16 * wave + 4 * q + e) * W + col] = cs[pb][e];
+            }
+          }
+        } else {
+          tot[0] += cs[0];
+          tot[1] += cs[1];
+        }
+        cs[0] = cs[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
 
   if constexpr (EPI == SPLIT_EPI_MEAN_T) {
+    if (a.seg_iters) return;     // split: the classifier kernel adds and scales the chunk sums
     // embedding rows [b][channel][col]: 16 consecutive columns per (channel, quarter-wave)
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
+      const f32x4_t tv = tot[pb];
       if (col < W) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = 16 * wave + 4 * q + e;
-          a.emb[((size_t)b * COUT + c) * W + col] = cs[pb][e] * a.inv_h;
+          a.emb[((size_t)b * COUT + c) * W + col] = tv[e] * a.inv_h;
         }
       }
     }
@@ -306,14 +334,15 @@ hipError_t launch_fold_pack_conv3x3_split(const float* w, const float* b, const 
 template <int CIN, int NW, int EPI, bool PIPE, bool SPLIT = true>
 static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
   auto kern = conv_split_kernel<CIN, NW, EPI, PIPE, SPLIT>;
-  constexpr int LDS = SplitCfg<CIN, SPLIT>::RING_BYTES + NW * 16 * 4;
+  constexpr int LDS = SplitCfg<CIN, SPLIT>::RING_BYTES + NW * 16 * 4 + (EPI == SPLIT_EPI_MEAN_T ? 64 * NW * 32 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, 1, 1), dim3(64 * NW), LDS, stream, a);
+  const int nseg = a.seg_iters ? ((a.H + 1) / 2 + a.seg_iters - 1) / a.seg_iters : 1;
+  hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, 1, nseg), dim3(64 * NW), LDS, stream, a);
   return hipGetLastError();
 }
 

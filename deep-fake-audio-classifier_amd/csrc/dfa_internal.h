@@ -95,6 +95,7 @@ struct dfa_ctx {
   int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
   int fuse_conv1 = 1;          // bf16 mode: blocks 1 and 2 in one kernel (conv12_fused.hip; fp32 features are rounded to bf16 on load); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
+  int time_split = -1;         // eval forward, small batches: -1 = automatic time-axis split, 0 = off, n > 0 = force n segments
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
@@ -172,7 +173,7 @@ hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int6
                         const DropCfg* drop = nullptr, const AugCfg* aug = nullptr);
 // linear.hip
 hipError_t launch_linear(const float* emb, const float* w, const float* bias, float* logits, int B, int K,
-                         hipStream_t s);
+                         hipStream_t s, int nseg = 1, size_t seg_stride = 0, float* emb_out = nullptr, float inv_h = 1.0f);
 // conv1d.hip
 hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
@@ -277,7 +278,8 @@ int train_conv_variant();   // conv3x3_inst_train.hip (process-wide test hook)
 void set_wgrad_variant(int v);   // wgrad_mfma.hip: bf16 weight-gradient kernel selection (process-wide test hook)
 hipError_t launch_pack_conv1_mfma(const float* w1, const float* b1, uint4* c1pack, float* c1bias, hipStream_t s);
 hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const uint4* c1pack, const float* c1bias,
-                               const uint4* wpack2, const float* bias2, void* a2, int B, int T, int F, hipStream_t s, int pipe = 1);
+                               const uint4* wpack2, const float* bias2, void* a2, int B, int T, int F, hipStream_t s, int pipe = 1,
+                               int seg_iters = 0);
 hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 struct ConvTArgs;

@@ -73,6 +73,9 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   compiler-scheduled twins (bit-identical results)
  *   "fuse_conv1"    1 (default) = CNN2D bf16 mode on bf16 features runs blocks 1+2 as one kernel, 0 = two kernels
  *   "block3_m16"    1 (default) = CNN2D bf16 block 3 on v_mfma_f32_16x16x32_bf16, 0 = the 32x32x16 kernel
+ *   "time_split"    -1 (default) = CNN2D eval forward splits the time axis over workgroups when the batch alone cannot fill
+ *                   the chip (B * strips below the resident-workgroup count, e.g. the reference's predict batch of 32), 0 =
+ *                   never, n > 0 = force n segments (results agree to fp32 summation order of the time mean)
  *   "dgrad_m16"     1 (default) = bf16 training: each data-gradient convolution is ONE launch of the 16x16x32 kernel
  *                   (conv_split.hip), 0 = the 32x32x16 kernels (block 3 as two Cin-half launches through fp32 partial sums)
  *   "wgrad_variant" 3 (default) = pipelined bf16 weight-gradient kernel, 30 = its compiler-scheduled twin, 2 = the

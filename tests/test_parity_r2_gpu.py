@@ -358,3 +358,39 @@ def test_bf16x3_is_eval_only(golden):
     model = _model_from_sd(sd, "bf16x3").train()
     with pytest.raises(ValueError):
         model(torch.zeros(2, 16, 180, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------ small batches: time-axis split
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_time_axis_split_is_bit_invariant(golden, prec):
+    """Small batches (the reference's predict.py default is 32) split the time axis over workgroups.  The time mean is always
+    summed in canonical chunks added in chunk order, so logits and embeddings must be IDENTICAL bit for bit whether the
+    axis is split automatically, not at all, or into any forced number of segments -- and for any batch size."""
+    from dfa_amd import _lib
+    sd, g = golden("cnn2d_eval")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    model = _model_from_sd(sd, prec)
+    gen = torch.Generator().manual_seed(41)
+    try:
+        for (B, T) in ((3, 321), (2, 130), (5, 37), (1, 700), (2, 9)):
+            stored = torch.randn(B, 180, T, generator=gen) * 3.2 - 0.07
+            x = stored.to("cuda").transpose(1, 2)
+            ctx.set_option("time_split", 0)
+            l0, e0 = model(x, return_embedding=True)
+            for split in (-1, 2, 3, 5, 8):
+                ctx.set_option("time_split", split)
+                l1, e1 = model(x, return_embedding=True)
+                assert torch.equal(e0, e1) and torch.equal(l0, l1), (prec, B, T, split, float((e0 - e1).abs().max()))
+                l2 = model(x)                                   # without the embedding output
+                assert torch.equal(l2, l0), (prec, B, T, split)
+        # against the references once more, with the split on
+        ctx.set_option("time_split", -1)
+        x = torch.from_numpy(g["t321.x_stored"]).to("cuda").transpose(1, 2)
+        got = model(x).cpu().numpy()
+        if prec == "bf16x3":
+            np.testing.assert_allclose(got, g["t321.logits"], atol=TOL_F32, rtol=0)
+        else:
+            want = O.cnn2d_forward(sd, np.swapaxes(g["t321.x_stored"], 1, 2), emulate="bf16")
+            np.testing.assert_allclose(got, want, atol=TOL_BF16_EMU_REL * max(1.0, float(np.abs(want).max())), rtol=0)
+    finally:
+        ctx.set_option("time_split", -1)
