@@ -12,7 +12,7 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr int kMaxSeg = 8;
+constexpr int kMaxSeg = 4;
 
 struct Cnn2dPlan {
   int H1, H2;               // rows after pool 1 / pool 2
@@ -32,7 +32,7 @@ Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
   p.emb_off = off;
   // small batches split the time axis over up to kMaxSeg workgroups per strip: one partial embedding per segment
   const int nstrips = (F + 31) / 32;
-  const size_t nemb = ((size_t)B * nstrips < 512) ? kMaxSeg : 1;
+  const size_t nemb = ((size_t)B * nstrips < 512) ? kMaxSeg + 1 : 1;
   off = align_up(off + nemb * (size_t)B * 128 * F * sizeof(float), 256);
   p.total = off;
   return p;
@@ -339,7 +339,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     a.in = a2; a.wpack = m.c3.wpack; a.bias = m.c3.bias; a.out = nullptr; a.emb = emb;
     a.B = B; a.H = pl.H2; a.W = F; a.COUT = 128; a.inv_h = 1.0f / (float)pl.H2; a.relu = 1; a.zero_page = ctx->zero_page;
     const int niter3 = (pl.H2 + 1) / 2;
-    const int chunk3 = 6 * std::max(1, (niter3 + 6 * kMaxSeg - 1) / (6 * kMaxSeg));   // canonical chunks: depends on T only, <= kMaxSeg of them
+    const int chunk3 = 6 * std::max(2, (niter3 + 6 * kMaxSeg - 1) / (6 * kMaxSeg));   // canonical chunks: depend on T only (12 iterations = 24 rows for T = 321), <= kMaxSeg of them
     if (prec == DFA_PREC_BF16X3) {
       a.chunk_iters = chunk3;
       a.seg_iters = seg_iters_for(niter3, B * nstrips32, 256, chunk3, ctx->time_split);
@@ -349,8 +349,8 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     }
     if (a.seg_iters) {           // one slab of (unscaled) sums per canonical chunk in the workspace; the classifier kernel adds them
       nseg3 = (niter3 + chunk3 - 1) / chunk3;
-      a.emb = (float*)(ws + pl.emb_off);
       a.emb_seg_stride = (size_t)B * 128 * F;
+      a.emb = (float*)(ws + pl.emb_off) + a.emb_seg_stride;     // slab 0 of the region is the reduced embedding
     }
     if (prec == DFA_PREC_BF16X3) {
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3_split(a, s, ctx->lds_pipe));
@@ -363,11 +363,11 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   }
   {
     ScopedSlot ts(ctx, 3);
-    if (nseg3 > 1)
-      DFA_HIP_CHECK(ctx, launch_linear((const float*)(ws + pl.emb_off), m.p[18], m.p[19], logits, B, 128 * F, s, nseg3,
-                                       (size_t)B * 128 * F, embedding, 1.0f / (float)pl.H2));
-    else
-      DFA_HIP_CHECK(ctx, launch_linear(emb, m.p[18], m.p[19], logits, B, 128 * F, s));
+    if (nseg3 > 1) {   // chunk slabs 1 .. nseg3 of the workspace region -> the embedding (slab 0 of the region, or the caller's buffer)
+      const size_t n = (size_t)B * 128 * F;
+      DFA_HIP_CHECK(ctx, launch_emb_reduce((const float*)(ws + pl.emb_off) + n, nseg3, n, n, 1.0f / (float)pl.H2, emb, s));
+    }
+    DFA_HIP_CHECK(ctx, launch_linear(emb, m.p[18], m.p[19], logits, B, 128 * F, s));
   }
   return DFA_OK;
 }

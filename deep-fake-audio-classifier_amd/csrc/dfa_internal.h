@@ -173,7 +173,8 @@ hipError_t launch_conv1(const void* x, int x_dtype, int64_t sb, int64_t st, int6
                         const DropCfg* drop = nullptr, const AugCfg* aug = nullptr);
 // linear.hip
 hipError_t launch_linear(const float* emb, const float* w, const float* bias, float* logits, int B, int K,
-                         hipStream_t s, int nseg = 1, size_t seg_stride = 0, float* emb_out = nullptr, float inv_h = 1.0f);
+                         hipStream_t s);
+hipError_t launch_emb_reduce(const float* parts, int nparts, size_t stride, size_t n, float inv_h, float* out, hipStream_t s);
 // conv1d.hip
 hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
