@@ -101,3 +101,131 @@ def cnn2d_forward_emulated(sd, x, emulate="bf16", return_embedding=False):
     emb = (a3.sum(dim=2, dtype=f64).float() * (1.0 / a3.shape[2])).flatten(1)
     logits = F.linear(emb.to(f64), _t(sd, "classifier.weight").to(f64), _t(sd, "classifier.bias").to(f64)).float()
     return (logits, emb) if return_embedding else logits
+
+
+# ---- rounding-faithful training step (bf16 storage mode) -----------------------------------------------------------
+class _StoreBF16(torch.autograd.Function):
+    """A tensor the product keeps in bf16 in BOTH directions: the forward value is rounded (storage of an activation) and
+    so is the gradient that arrives for it (storage of the matching data gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.float().to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float().to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundSTE(torch.autograd.Function):
+    """forward: round to bf16; backward: identity (the value is stored rounded, its consumers' gradient passes unchanged)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.float().to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """forward: identity; backward: the TOTAL gradient of this node is rounded to bf16 (dz of a BatchNorm backward pass)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float().to(torch.bfloat16).to(g.dtype)
+
+
+def cnn2d_train_step_emulated(sd, x, y, label_smoothing=0.0, emulate="bf16"):
+    """One CNN2D training forward/backward (dropout 0) restated with the ROUNDING POINTS of the product's bf16 training
+    mode (src/train.py:71-76 over src/model.py:13-39 in train mode): a1, z2, a2, z3 and their gradients da1, dz2, da2, dz3
+    are stored in bf16, the MFMA convolutions of blocks 2 and 3 (forward, data gradient, weight gradient) take bf16
+    weights and bf16 activations, BatchNorm batch statistics come from the unrounded accumulators, block 1 / the time mean /
+    the classifier / the loss are fp32.  Everything else is float64 with torch autograd.  emulate=None removes every
+    rounding: the result must then equal the reference's autograd goldens (pins the restatement).
+    Returns (logits [B], loss, {parameter name: gradient}) with the names of the model's named_parameters()."""
+    f64 = torch.float64
+    on = emulate == "bf16"
+    if emulate not in (None, "bf16"):
+        raise ValueError(emulate)
+    P = {k: _t(sd, k).to(f64).clone().requires_grad_(True) for k in sd
+         if k.endswith(("weight", "bias")) and not k.endswith(("running_mean", "running_var"))}
+    store = _StoreBF16.apply if on else (lambda t: t)
+    rnd = _RoundSTE.apply if on else (lambda t: t)
+    rgrad = _RoundGrad.apply if on else (lambda t: t)
+
+    def bn_train(z, pfx):       # batch statistics of the accumulators, normalisation of the stored value
+        za = rgrad(z)
+        mean = za.mean(dim=(0, 2, 3), keepdim=True)
+        var = za.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        zs = rnd(za)
+        return (zs - mean) / torch.sqrt(var + 1e-5) * P[pfx + ".weight"][None, :, None, None] + P[pfx + ".bias"][None, :, None, None]
+
+    xb = (x.to(torch.bfloat16) if on else x).to(f64).unsqueeze(1)
+    # block 1: fp32 VALU convolution from x, z1 is never stored (no rounding of z1 or dz1)
+    z1 = F.conv2d(xb, P["conv.0.weight"], P["conv.0.bias"], padding=1)
+    m1 = z1.mean(dim=(0, 2, 3), keepdim=True)
+    v1 = z1.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    y1 = (z1 - m1) / torch.sqrt(v1 + 1e-5) * P["conv.1.weight"][None, :, None, None] + P["conv.1.bias"][None, :, None, None]
+    a1 = store(F.avg_pool2d(F.relu(y1), (2, 1)))
+    w2 = P["conv.5.weight"]
+    w2b = w2 + (rnd(w2) - w2).detach() if on else w2
+    a2 = store(F.avg_pool2d(F.relu(bn_train(F.conv2d(a1, w2b, P["conv.5.bias"], padding=1), "conv.6")), (2, 1)))
+    w3 = P["conv.10.weight"]
+    w3b = w3 + (rnd(w3) - w3).detach() if on else w3
+    a3 = F.relu(bn_train(F.conv2d(a2, w3b, P["conv.10.bias"], padding=1), "conv.11"))
+    emb = a3.mean(dim=2).flatten(1)
+    logits = F.linear(emb, P["classifier.weight"], P["classifier.bias"]).squeeze(-1)
+    ys = y.to(f64) * (1.0 - label_smoothing) + 0.5 * label_smoothing if label_smoothing > 0 else y.to(f64)
+    loss = F.binary_cross_entropy_with_logits(logits, ys)
+    loss.backward()
+    return logits.detach().float(), float(loss), {k: v.grad.float() for k, v in P.items()}
+
+
+@torch.no_grad()
+def cae_forward_emulated(sd, x, emulate="bf16"):
+    """ConvAutoencoder.forward (eval, src/model_cae.py:83-125) restated with the ROUNDING POINTS of the product's bf16 mode:
+    encoder block 1 in fp32 (folded weights, 1/4 pool factor after the ReLUs) with its output stored in bf16; encoder
+    blocks 2-4 and decoder blocks 1-3 with bf16 weights (BatchNorm folded; the encoder's 1/4 pool factor folded into
+    weights and bias before the rounding), fp32 bias, float64 sums rounded once, outputs stored in bf16 (the latent map is
+    the bf16 value); decoder block 4 in fp32 from the bf16 d3.  emulate=None: no rounding (must equal the reference).
+    Returns (reconstruction [B,T,F], latent [B,256,T/16,F/16])."""
+    if emulate not in (None, "bf16"):
+        raise ValueError(emulate)
+    rnd = _bf16r if emulate == "bf16" else (lambda t: t)
+    f64 = torch.float64
+
+    def fold(conv, bn, transposed=False):
+        s = _t(sd, bn + ".weight").float() / torch.sqrt(_t(sd, bn + ".running_var").float() + 1e-5)
+        w = _t(sd, conv + ".weight").float()
+        w = w * (s[None, :, None, None] if transposed else s[:, None, None, None])
+        b = (_t(sd, conv + ".bias").float() - _t(sd, bn + ".running_mean").float()) * s + _t(sd, bn + ".bias").float()
+        return w, b
+    h = x.float().unsqueeze(1)
+    w, b = fold("encoder.0", "encoder.1")
+    z = F.relu(F.conv2d(h.to(f64), w.to(f64), b.to(f64), padding=1).float())
+    h = rnd(F.avg_pool2d(z, 2))                                         # 0.25 * sum of four ReLUs in fp32
+    for c, bnk in ((4, 5), (8, 9), (12, 13)):
+        w, b = fold(f"encoder.{c}", f"encoder.{bnk}")
+        wq, bq = rnd(w * 0.25), b * 0.25
+        z = F.relu(F.conv2d(h.to(f64), wq.to(f64), bq.to(f64), padding=1).float())
+        H2, W2 = z.shape[2] // 2, z.shape[3] // 2
+        z = z[:, :, :2 * H2, :2 * W2]
+        h = rnd((z[:, :, 0::2, 0::2] + z[:, :, 1::2, 0::2]) + (z[:, :, 0::2, 1::2] + z[:, :, 1::2, 1::2]))
+    latent = h
+    d = latent
+    for c, bnk, opad in ((0, 1, (0, 0)), (3, 4, (0, 1)), (6, 7, (0, 0))):
+        w, b = fold(f"decoder.{c}", f"decoder.{bnk}", transposed=True)
+        d = rnd(F.relu(F.conv_transpose2d(d.to(f64), rnd(w).to(f64), b.to(f64), stride=2, output_padding=opad).float()))
+    d = F.conv_transpose2d(d.to(f64), _t(sd, "decoder.9.weight").to(f64), _t(sd, "decoder.9.bias").to(f64), stride=2).float()
+    T, Tr = x.size(1), d.size(2)
+    if Tr < T:
+        d = F.pad(d, (0, 0, 0, T - Tr))
+    elif Tr > T:
+        d = d[:, :, :T, :]
+    return d.squeeze(1), latent

@@ -188,3 +188,43 @@ def test_emulated_bf16_oracle_sits_at_bf16_distance_from_reference_and_matches_t
         np.testing.assert_allclose(emb.numpy(), inter["embedding"], atol=2e-4, rtol=1e-3)
     tw0 = R.cnn2d_forward_emulated(sd, torch.from_numpy(g["t64.x_stored"]).transpose(1, 2), None)
     np.testing.assert_allclose(tw0.numpy(), g["t64.logits"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("tag,eps", [("ls0", 0.0), ("ls05", 0.05)])
+def test_emulated_training_oracle_without_rounding_equals_reference_autograd(golden, tag, eps):
+    """oracle.torch_ref.cnn2d_train_step_emulated(emulate=None) -- the float64 autograd restatement the bf16 training oracle
+    is built on -- reproduces the reference's own loss and per-parameter gradients (tests/golden/cnn2d_train.npz)."""
+    import torch
+    from oracle import torch_ref as R
+    _, g = golden("cnn2d_train")
+    sd = {k[len("init.sd."):]: v for k, v in g.items() if k.startswith("init.sd.")}
+    x = torch.from_numpy(g[f"{tag}.x"]).transpose(1, 2)
+    y = torch.from_numpy(g[f"{tag}.y"])
+    logits, loss, grads = R.cnn2d_train_step_emulated(sd, x, y, eps, emulate=None)
+    np.testing.assert_allclose(logits.numpy(), g[f"{tag}.logits"], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(loss, g[f"{tag}.loss"], rtol=1e-5)
+    for name, got in grads.items():
+        want = g[f"{tag}.grad.{name}"]
+        if name in ("conv.0.bias", "conv.5.bias", "conv.10.bias"):
+            continue                                   # exactly-zero gradients: rounding noise on both sides
+        scale = max(np.abs(want).max(), 1e-6)
+        np.testing.assert_allclose(got.numpy(), want, atol=2e-4 * scale + 1e-7, rtol=2e-3, err_msg=name)
+    # and the bf16 form sits at bf16 distance from it (the emulation changes something, but not much)
+    _, _, g16 = R.cnn2d_train_step_emulated(sd, x, y, eps, emulate="bf16")
+    rel = max(float((g16[n] - grads[n]).abs().max() / max(float(grads[n].abs().max()), 1e-6)) for n in grads
+              if n not in ("conv.0.bias", "conv.5.bias", "conv.10.bias"))
+    assert 1e-4 < rel < 0.3, rel
+
+
+def test_emulated_cae_oracle_without_rounding_equals_reference(golden):
+    import torch
+    from oracle import torch_ref as R
+    sd, g = golden("cae_eval")
+    for tag in ("t64", "t70"):
+        x = torch.from_numpy(g[f"{tag}.x"])
+        recon, latent = R.cae_forward_emulated(sd, x, emulate=None)
+        np.testing.assert_allclose(latent.numpy(), g[f"{tag}.latent"], atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(recon.numpy(), g[f"{tag}.recon"], atol=2e-5, rtol=1e-5)
+        r16, l16 = R.cae_forward_emulated(sd, x, emulate="bf16")
+        d = float((r16 - recon).abs().max())
+        assert 1e-5 < d < 0.08, d

@@ -95,12 +95,28 @@ def test_train_bf16_mode_and_dropout_run(golden):
     model = _fresh_model(g, precision="bf16")
     loss = torch.nn.BCEWithLogitsLoss()(model(x).squeeze(-1), y)
     loss.backward()
-    for name, p in model.named_parameters():
-        if name in NOISE_KEYS:
-            continue
-        want = g[f"ls0.grad.{name}"]
-        rel = np.abs(p.grad.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-6)
-        assert rel < 0.25, (name, rel)      # bf16 storage of z/dz on a 4 x 16-frame batch: coarse agreement only
+    # Round 2: held to the ROUNDING-FAITHFUL training oracle (oracle/torch_ref.py cnn2d_train_step_emulated: float64 autograd
+    # with bf16 rounding exactly where the kernels store a1, z2, a2, z3, da1, dz2, da2, dz3 and the MFMA weights; without
+    # the roundings it reproduces the reference's autograd goldens, tests/test_oracle_golden.py).  Measured on MI355X
+    # (tools/gpu_train_emu_probe.py): 0.04 % .. 0.9 % of each gradient's scale, where the fp32 reference sits 1.4 % .. 12 %
+    # away -- the bound is 2 % instead of round 1's 25 %.
+    from oracle import torch_ref as R
+    sd = {k[len("init.sd."):]: v for k, v in g.items() if k.startswith("init.sd.")}
+    gen = torch.Generator().manual_seed(3)
+    cases = [(torch.from_numpy(g["ls0.x"]).transpose(1, 2), torch.from_numpy(g["ls0.y"]), None),   # bf16 features, as the oracle rounds them
+             ((torch.randn(16, 180, 64, generator=gen) * 3.2 - 0.07).transpose(1, 2), (torch.rand(16, generator=gen) > 0.5).float(), None)]
+    for xc, yc, m in cases:
+        if m is None:
+            m = _fresh_model(g, precision="bf16")
+            torch.nn.BCEWithLogitsLoss()(m(xc.to("cuda").to(torch.bfloat16)).squeeze(-1), yc.to("cuda")).backward()
+        _, _, emu = R.cnn2d_train_step_emulated(sd, xc, yc, 0.0, "bf16")
+        _, _, ref = R.cnn2d_train_step_emulated(sd, xc, yc, 0.0, None)
+        for name, p in m.named_parameters():
+            if name in NOISE_KEYS:
+                continue
+            scale = max(float(ref[name].abs().max()), 1e-6)
+            rel = float((p.grad.float().cpu() - emu[name]).abs().max()) / scale
+            assert rel < 0.02, (name, tuple(xc.shape), rel)
     model = _fresh_model(g)
     model.dropout = 0.3
     torch.manual_seed(0)
