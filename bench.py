@@ -242,6 +242,37 @@ def gpu_end_to_end(torch, device, model_state, features_path, n, cpu_pred_path):
     return res
 
 
+def small_batch_metric(torch, device, steps=200, warmup=30):
+    """The reference's predict.py default batch (32) and batch 1: a step is latency-bound there (one workgroup walk down the
+    time axis per strip); the eval forward splits the time axis over workgroups (context option time_split, bit-identical
+    results).  utterances/s and ms per forward, bf16 mode, with the split (default) and without."""
+    from dfa_amd import _lib
+    ctx = _lib.Context.get(device)
+    model = build_model(torch, device, "bf16")
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    try:
+        for Bs in (1, 32):
+            x = (torch.randn(Bs, F, T, generator=g) * 3.2 - 0.07).to(device=device, dtype=torch.bfloat16).transpose(1, 2)
+            rec = {}
+            for tag, opt in (("time_split", -1), ("no_split", 0)):
+                ctx.set_option("time_split", opt)
+                for _ in range(warmup):
+                    model(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model(x)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                rec[tag] = {"ms": round(dt * 1e3, 4), "value": round(Bs / dt, 1)}
+            out[f"batch_{Bs}"] = rec
+    finally:
+        ctx.set_option("time_split", -1)
+    out["unit"] = "utterances/s"
+    return out
+
+
 TRAIN_FLOPS_PER_UTT = 9_621_849_600      # SURVEY.md section 8(d): fwd 3.218 G + wgrad 3.218 G + dgrad(conv2,3) + linear 3.185 G
 
 
@@ -406,6 +437,7 @@ def main():
                                                                     zip(r16["logits_sample"], r32["logits_sample"])), 5)},
         }
         if world == 1:
+            line["small_batch"] = small_batch_metric(torch, device)
             line["train_step"] = train_step_metric(torch, device, B)
             line["other_models"] = other_models_metric(torch, device, B)
         if world == 1 and not args.no_cpu_baseline:
