@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
       for (int e = 0; e < 3; ++e) {
         const int s = xcol[k] - e;
         const bool ok = (k * 256 + tid < NX) && s >= 0 && s < 32;
-        *(unsigned short*)(smem + (ok ? base + s * 8 + e * 2 : DUMMY_OFF)) = v;
+        const int off = ok ? base + s * 8 + e * 2 : DUMMY_OFF;
+        if constexpr (PIPE) {   // through asm so that the store's place in the in-order LDS queue is known to the counted waits
+          asm volatile("ds_write_b16 %0, %1" : : "v"(lds0 + off), "v"((unsigned)v) : "memory");
+        } else {
+          *(unsigned short*)(smem + off) = v;
+        }
       }
     }
   };
@@ -196,7 +201,12 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
       const unsigned b0 = pack_bf16x2(st.v[4 * g + 4], st.v[4 * g + 5]), b1 = pack_bf16x2(st.v[4 * g + 6], st.v[4 * g + 7]);
       const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
       const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-      *(uint4*)(dst + (((g + h) ^ c1_sw) << 4)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      if constexpr (PIPE) {
+        const u32x4_t pk = {s0[0], s1[0], s0[1], s1[1]};
+        asm volatile("ds_write_b128 %0, %1" : : "v"(lds0 + ringblk * (BR * ROWB) + c1_dst + (((g + h) ^ c1_sw) << 4)), "v"(pk) : "memory");
+      } else {
+        *(uint4*)(dst + (((g + h) ^ c1_sw) << 4)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
     }
   };
   auto produce_now = [&](int j, int ringblk) {
@@ -226,14 +236,20 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   const int it0 = a.seg_iters ? (int)blockIdx.y * a.seg_iters : 0;
   const int niter_seg = a.seg_iters ? min(niter, it0 + a.seg_iters) : niter;
   // ---- prologue: windows of blocks it0, it0+1 -> ring blocks 0, 1; windows of block it0+2
+  // the window / ring stores of the pipelined build go out through asm: the compiler does not know they are in flight, so the
+  // waits in front of the prologue's barriers are explicit (in the loop the last counted wait of a unit is lgkmcnt(0))
+  auto lds_drain = [&]() { if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
   __syncthreads();                 // window pads / bias written
   x_load(it0); x_store(0);
   x_load(it0 + 1); x_store(1);
+  lds_drain();
   __syncthreads();
   produce_now(it0, 0);
   produce_now(it0 + 1, 1);
+  lds_drain();
   __syncthreads();
   x_load(it0 + 2); x_store(0);
+  lds_drain();
   __syncthreads();
 
   // ---- block 2 unit (conv3x3_mfma.h, <bf16, CIN 32, POOL_H2>, asm-pipelined fragment reads) + the block-1 tile of
@@ -260,7 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
         constexpr int i = c / (3 * NKG), dx = (c / NKG) % 3, kg = c % NKG;
-        constexpr int young = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
+        // LDS operations complete in order: the wait for read c may leave outstanding everything issued after it -- the
+        // younger reads AND the block-1 / window stores (asm, so their position is known) that went out after read c:
+        // the 2 ring stores issued behind consume step C_STORE and the 3 * NXLD window stores behind C_XSTORE.
+        constexpr int young_r = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
+        constexpr int young = young_r + ((c > C_STORE && c <= C_STORE + PF - 1 && c < NR) ? 2 : 0) +
+                              ((c > C_XSTORE && c <= C_XSTORE + PF - 1 && c < NR) ? 3 * NXLD : 0);
         if constexpr (PIPE) lds_wait<young>(xbuf[c % PF]);
         const uint4 xv = __builtin_bit_cast(uint4, xbuf[c % PF]);
         if constexpr (i <= 2) acc0 = Mma<bf16_t>::run(w[i * 3 + dx][kg], xv, acc0);
