@@ -70,6 +70,7 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU per step")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--small-batch", action="store_true", help="add the batch 1 / batch 32 latency leg (time-axis split on / off)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     p.add_argument("--e2e-utts", type=int, default=512, help="utterances in the end-to-end (features.pkl -> prediction.pkl) legs")
     return p.parse_args()
@@ -437,7 +438,8 @@ def main():
                                                                     zip(r16["logits_sample"], r32["logits_sample"])), 5)},
         }
         if world == 1:
-            line["small_batch"] = small_batch_metric(torch, device)
+            if args.small_batch:      # opt-in: its B = 1 / 32 launches would mix into the per-kernel averages of a rocprofv3 run
+                line["small_batch"] = small_batch_metric(torch, device)
             line["train_step"] = train_step_metric(torch, device, B)
             line["other_models"] = other_models_metric(torch, device, B)
         if world == 1 and not args.no_cpu_baseline:
