@@ -235,38 +235,40 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) tot[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const int chunk = a.chunk_iters > 0 ? a.chunk_iters : niter_all + 3;
-  for (int it = it0; it < niter; it += 3) {
-    iteration(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
-    if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
+  // outer loop over the canonical chunks of the time mean (chunk_iters iterations, a multiple of 6; one chunk = the whole
+  // walk when unset), inner loop = the ring walk itself, unchanged; a chunk's sum is flushed once, outside the hot loop
+  const int chunk = (!TRAIN && a.chunk_iters > 0) ? a.chunk_iters : niter_all + 3;
+  for (int c0 = it0; c0 < niter; c0 += chunk) {
+    const int cend = min(niter, c0 + chunk);
+    for (int it = c0; it < cend; it += 3) {
+      iteration(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < cend) iteration(std::integral_constant<int, 1>{}, it + 1);
+      if (it + 2 < cend) iteration(std::integral_constant<int, 2>{}, it + 2);
+    }
     if constexpr (!TRAIN) {
-      const int done = it + 3;
-      if (done % chunk == 0 || done >= niter) {          // wave-uniform: a canonical chunk of the time mean is complete
-        if (a.seg_iters) {                                 // split: the chunk sum (unscaled) goes to its own slab
-          float* e0 = a.emb + (size_t)(it / chunk) * a.emb_seg_stride;
-#pragma unroll
-          for (int ca = 0; ca < 2; ++ca)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-              const int col = f0 + 16 * pb + p;
-              if (col < W) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  e0[((size_t)b * COUT + cout_base + nsl * 32 + 16 * ca + 4 * q + e) * W + col] = cs[ca][pb][e];
-              }
-            }
-        } else {
-#pragma unroll
-          for (int ca = 0; ca < 2; ++ca)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) tot[ca * 2 + pb] += cs[ca][pb];
-        }
+      if (a.seg_iters) {                                 // split: the chunk sum (unscaled) goes to its own slab
+        float* e0 = a.emb + (size_t)(c0 / chunk) * a.emb_seg_stride;
 #pragma unroll
         for (int ca = 0; ca < 2; ++ca)
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) cs[ca][pb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int pb = 0; pb < 2; ++pb) {
+            const int col = f0 + 16 * pb + p;
+            if (col < W) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                e0[((size_t)b * COUT + cout_base + nsl * 32 + 16 * ca + 4 * q + e) * W + col] = cs[ca][pb][e];
+            }
+          }
+      } else {
+#pragma unroll
+        for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) tot[ca * 2 + pb] += cs[ca][pb];
       }
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) cs[ca][pb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
 

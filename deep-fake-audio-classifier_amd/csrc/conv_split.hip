@@ -242,30 +242,30 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   // MEAN_T: running total over the canonical chunks of the time mean (ConvArgs::chunk_iters), 8 floats per lane in LDS
   f32x4_t* const tot = (f32x4_t*)(smem + C::RING_BYTES + COUT * 4) + tid * 2;
   if constexpr (EPI == SPLIT_EPI_MEAN_T) tot[0] = tot[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int chunk = a.chunk_iters > 0 ? a.chunk_iters : niter_all + 3;
-  for (int it = it0; it < niter; it += 3) {
-    iteration(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < niter) iteration(std::integral_constant<int, 1>{}, it + 1);
-    if (it + 2 < niter) iteration(std::integral_constant<int, 2>{}, it + 2);
+  const int chunk = (EPI == SPLIT_EPI_MEAN_T && a.chunk_iters > 0) ? a.chunk_iters : niter_all + 3;
+  for (int c0 = it0; c0 < niter; c0 += chunk) {          // canonical chunks of the time mean; the inner loop is the ring walk
+    const int cend = min(niter, c0 + chunk);
+    for (int it = c0; it < cend; it += 3) {
+      iteration(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < cend) iteration(std::integral_constant<int, 1>{}, it + 1);
+      if (it + 2 < cend) iteration(std::integral_constant<int, 2>{}, it + 2);
+    }
     if constexpr (EPI == SPLIT_EPI_MEAN_T) {
-      const int done = it + 3;
-      if (done % chunk == 0 || done >= niter) {          // wave-uniform: a canonical chunk is complete
-        if (a.seg_iters) {
-          float* e0 = a.emb + (size_t)(it / chunk) * a.emb_seg_stride;
+      if (a.seg_iters) {
+        float* e0 = a.emb + (size_t)(c0 / chunk) * a.emb_seg_stride;
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            const int col = f0 + 16 * pb + p;
-            if (col < W) {
+        for (int pb = 0; pb < 2; ++pb) {
+          const int col = f0 + 16 * pb + p;
+          if (col < W) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) e0[((size_t)b * COUT + 16 * wave + 4 * q + e) * W + col] = cs[pb][e];
-            }
+            for (int e = 0; e < 4; ++e) e0[((size_t)b * COUT + 16 * wave + 4 * q + e) * W + col] = cs[pb][e];
           }
-        } else {
-          tot[0] += cs[0];
-          tot[1] += cs[1];
         }
-        cs[0] = cs[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      } else {
+        tot[0] += cs[0];
+        tot[1] += cs[1];
       }
+      cs[0] = cs[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
 
