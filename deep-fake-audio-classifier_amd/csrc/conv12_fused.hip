@@ -21,6 +21,8 @@
 //   global-load the features of ring block it+3 -> registers;  block-2 MFMA unit on ring blocks it, it+1 with the wave's
 //   block-1 tile of ring block it+2 (window buffer it&1 -> ring slot (it+2)%3) and the register -> window buffer
 //   (it+3)&1 stores threaded through its MFMA stream, so the block-1 VALU work hides in the MFMA shadow.
+#include <stdlib.h>
+
 #include "dfa_internal.h"
 
 namespace dfa {
@@ -254,6 +256,21 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
 
   // ---- block 2 unit (conv3x3_mfma.h, <bf16, CIN 32, POOL_H2>, asm-pipelined fragment reads) + the block-1 tile of
   // ring block it+2 and the window stores of block it+3 at fixed points of its MFMA stream
+  // The packed pooled outputs of a unit are kept (8 registers) and leave -- half-wave swaps + two 16-byte stores -- from inside
+  // the NEXT unit's MFMA stream; the feature loads of ring block it+3 are issued from inside the stream as well: neither
+  // stands alone between two MFMA streams any more (per-wave stamps, one wave per SIMD: the epilogue was 536 and the
+  // loads 301 of an iteration's 3388 cycles).
+  unsigned pq[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  bf16_t* po = obase;
+  bool pok = false;
+  auto flush_pending = [&]() {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const auto s0 = __builtin_amdgcn_permlane32_swap(pq[4 * g], pq[4 * g + 2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(pq[4 * g + 1], pq[4 * g + 3], false, false);
+      if (pok) *(uint4*)(po + 16 * g) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
+  };
   auto unit = [&](auto ph_c, auto rp_c, int it) {
     constexpr int PH = decltype(ph_c)::value, RPI = decltype(rp_c)::value;
     f32x16_t acc0, acc1;
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     constexpr int S_RELU0 = 9 * NKG + 2;
     // consume steps carrying block-1 pieces: the window reads are issued behind fragment read 1; by the wait of consume
     // step 1 (all but the 3 youngest reads landed, those being fragment reads 2..4) they are in registers
-    constexpr int C_MFMA = 2, C_RELU = 8, C_STORE = 12, C_XSTORE = 16;
+    constexpr int C_MFMA = 2, C_XLOAD = 4, C_PSTORE = 6, C_RELU = 8, C_STORE = 12, C_XSTORE = 16;
     u32x4_t xbuf[PF];
     C1State c1;
     auto step = [&](auto s_c) {
@@ -287,6 +304,8 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
         if constexpr (i <= 2) acc0 = Mma<bf16_t>::run(w[i * 3 + dx][kg], xv, acc0);
         if constexpr (i >= 1) acc1 = Mma<bf16_t>::run(w[(i - 1) * 3 + dx][kg], xv, acc1);
         if constexpr (c == C_MFMA) c1_mfma(c1);
+        if constexpr (c == C_XLOAD) x_load(it + 3);
+        if constexpr (c == C_PSTORE) flush_pending();
         if constexpr (c == C_RELU) c1_relu(c1, it + 2);
         if constexpr (c == C_STORE) c1_store(c1, (PH + 2) % 3);
         if constexpr (c == C_XSTORE) x_store((it + 3) & 1);
@@ -316,22 +335,20 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = acc0[i] + relu1(acc1[i], rlim);
-    bf16_t* o = obase + (size_t)to * (W * 64);
-    const bool ok = (to < Ho) && col_ok;
+    po = obase + (size_t)to * (W * 64);
+    pok = (to < Ho) && col_ok;
 #pragma unroll
-    for (int g = 0; g < 4; g += 2) {
-      const unsigned a0 = pack_bf16x2(v[4 * g], v[4 * g + 1]), a1 = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
-      const unsigned b0 = pack_bf16x2(v[4 * g + 4], v[4 * g + 5]), b1 = pack_bf16x2(v[4 * g + 6], v[4 * g + 7]);
-      const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-      if (ok) *(uint4*)(o + 8 * g) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    for (int g = 0; g < 2; ++g) {          // channel groups (2g, 2g+1) -> after the swap lanes own 8 consecutive channels
+      pq[4 * g] = pack_bf16x2(v[8 * g], v[8 * g + 1]);
+      pq[4 * g + 1] = pack_bf16x2(v[8 * g + 2], v[8 * g + 3]);
+      pq[4 * g + 2] = pack_bf16x2(v[8 * g + 4], v[8 * g + 5]);
+      pq[4 * g + 3] = pack_bf16x2(v[8 * g + 6], v[8 * g + 7]);
     }
   };
 
   // Every iteration produces ring block it+2 and the windows of block it+3, also past the end of the image (the row
   // checks turn those into zeros that nobody reads): no wave-divergent or data-dependent branch in the loop.
   auto iteration = [&](auto ph_c, int it) {
-    x_load(it + 3);
     stamp(0);
     if (mg == 0) unit(ph_c, std::integral_constant<int, 0>{}, it);
     else unit(ph_c, std::integral_constant<int, 1>{}, it);
@@ -345,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     if (it + 1 < niter_seg) iteration(std::integral_constant<int, 1>{}, it + 1);
     if (it + 2 < niter_seg) iteration(std::integral_constant<int, 2>{}, it + 2);
   }
+  flush_pending();                 // the last unit's outputs
 #ifdef DFA_STAMPS
   if (lane == 0 && blockIdx.x < 2048) {
     long long* dd = g_diag12 + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -385,14 +403,17 @@ template <typename TX, bool PIPE>
 static hipError_t launch_conv12_t(const Conv12Args& a, int B, hipStream_t s) {
   auto kern = conv12_fused_kernel<TX, PIPE>;
   static bool attr_set = false;
+  static int lds_bytes = c12::LDS_BYTES;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, c12::LDS_BYTES);
+    // diagnostic: DFA_C12_LDS_PAD=<bytes> pads the dynamic LDS request (e.g. 60000 -> one workgroup per CU, one wave per SIMD)
+    if (const char* pad = getenv("DFA_C12_LDS_PAD")) lds_bytes += atoi(pad);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int niter = (a.H1 + c12::BR - 1) / c12::BR;
   const int nseg = a.seg_iters ? (niter + a.seg_iters - 1) / a.seg_iters : 1;
-  hipLaunchKernelGGL(kern, dim3(B * a.nstrips, nseg), dim3(256), c12::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(B * a.nstrips, nseg), dim3(256), lds_bytes, s, a);
   return hipGetLastError();
 }
 
