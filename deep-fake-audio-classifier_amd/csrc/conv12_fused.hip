@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
 #ifdef DFA_STAMPS   // diagnostic build (make stamps): per-wave cycle split, printed by the launcher
   long long seg[6] = {0, 0, 0, 0, 0, 0};
   long long t_prev = __builtin_amdgcn_s_memtime();
-  const long long t_begin = t_prev;
+  const long long t_begin = t_prev, r_begin = __builtin_amdgcn_s_memrealtime();
   auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg[k] += t - t_prev; t_prev = t; };
 #else
   auto stamp = [&](int) {};
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
   if (lane == 0 && blockIdx.x < 2048) {
     long long* dd = g_diag12 + ((size_t)blockIdx.x * 4 + wave) * 8;
     for (int k = 0; k < 6; ++k) dd[k] = seg[k];
+    dd[4] = __builtin_amdgcn_s_memrealtime() - r_begin;     // 100 MHz ticks: with the shader-clock lifetime -> the clock held
     dd[6] = t_begin;
     dd[7] = __builtin_amdgcn_s_memtime();
   }
@@ -432,13 +433,14 @@ hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t s
 #ifdef DFA_STAMPS
   {
     static int calls = 0;
-    if (++calls == 40) {
+    if (++calls == 4000) {        // seconds of back-to-back launches: the clock has settled
       static long long hbuf[2048 * 4 * 8];
       hipDeviceSynchronize();
       hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag12), sizeof(hbuf));
       const int nw = (B * a.nstrips < 2048 ? B * a.nstrips : 2048) * 4;
       double m[8] = {0};
       for (int i = 0; i < nw; ++i) { for (int k = 0; k < 6; ++k) m[k] += hbuf[i * 8 + k]; m[6] += hbuf[i * 8 + 7] - hbuf[i * 8 + 6]; }
+      fprintf(stderr, "[stamps conv12] in-kernel clock %.3f GHz (shader cycles / 100 MHz real-time ticks, mean over waves)\n", m[6] / (m[4] * 10.0));
       fprintf(stderr, "[stamps conv12] waves %d  mean cycles/wave: x_load %.0f  mfma_stream %.0f  epilogue %.0f  barrier %.0f  prologue %.0f  lifetime %.0f\n",
               nw, m[0] / nw, m[1] / nw, m[2] / nw, m[3] / nw, m[5] / nw, m[6] / nw);
     }

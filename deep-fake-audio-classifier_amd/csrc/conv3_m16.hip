@@ -15,6 +15,9 @@
 // the ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) this is conflict-free for all three tap columns, both
 // pixel tiles and both k-groups (exhaustive check in tests/test_host_api.py::test_m16_swizzle_is_conflict_free).
 #include "dfa_internal.h"
+#include <algorithm>
+#include <stdio.h>
+#include <vector>
 
 namespace dfa {
 
@@ -36,6 +39,10 @@ __device__ __forceinline__ f32x4_t mma16(const uint4& w, const uint4& x, f32x4_t
 // TRAIN = true: the train-mode forward of the same layer (src/train.py:71): the pre-BatchNorm output z is stored (bf16)
 // and the per-channel sum / sum of squares of the stored values ride along for the batch statistics (per-workgroup
 // partials in conv3x3_mfma's STATS layout); the weights come unfolded, ReLU and the time mean are separate passes.
+#ifdef DFA_STAMPS   // diagnostic build (make stamps): shader-clock and real-time stamps around the main loop -> the clock the chip holds
+static __device__ long long g_diag16[4096 * 2];
+#endif
+
 template <bool PIPE, bool TRAIN = false>
 __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   using namespace m16;
@@ -238,6 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   // outer loop over the canonical chunks of the time mean (chunk_iters iterations, a multiple of 6; one chunk = the whole
   // walk when unset), inner loop = the ring walk itself, unchanged; a chunk's sum is flushed once, outside the hot loop
   const int chunk = (!TRAIN && a.chunk_iters > 0) ? a.chunk_iters : niter_all + 3;
+#ifdef DFA_STAMPS
+  const long long st_c = __builtin_amdgcn_s_memtime(), st_r = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int c0 = it0; c0 < niter; c0 += chunk) {
     const int cend = min(niter, c0 + chunk);
     for (int it = c0; it < cend; it += 3) {
@@ -271,6 +281,12 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
         for (int pb = 0; pb < 2; ++pb) cs[ca][pb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
+#ifdef DFA_STAMPS
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) {
+    g_diag16[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c;
+    g_diag16[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+  }
+#endif
 
   if constexpr (TRAIN) {
     // per-channel sums over this workgroup's pixels: the 16 pixel lanes of a quarter-wave hold the same 8 channels
@@ -359,6 +375,25 @@ static hipError_t launch_m16_t(const ConvArgs& a, hipStream_t stream) {
   }
   const int nseg = a.seg_iters ? ((a.H + m16::BR - 1) / m16::BR + a.seg_iters - 1) / a.seg_iters : 1;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, a.COUT / 128, nseg), dim3(256), m16::LDS_BYTES, stream, a);
+#ifdef DFA_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 4000) {          // after seconds of back-to-back launches on random data: the clock has settled
+      static long long hbuf[4096 * 2];
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag16), sizeof(hbuf));
+      const int n = a.B * a.nstrips < 4096 ? a.B * a.nstrips : 4096;
+      std::vector<double> ghz;
+      double cyc = 0;
+      for (int i = 0; i < n; ++i)
+        if (hbuf[2 * i + 1] > 0) { ghz.push_back(hbuf[2 * i] / (hbuf[2 * i + 1] * 10.0)); cyc += hbuf[2 * i]; }
+      std::sort(ghz.begin(), ghz.end());
+      if (!ghz.empty())
+        fprintf(stderr, "[stamps m16] workgroups %zu  main loop %.0f shader cycles/wave  in-kernel clock median %.3f GHz (min %.3f max %.3f)\n",
+                ghz.size(), cyc / ghz.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back());
+    }
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -11,5 +11,5 @@ x = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to(device=dev, dtype=
 ctx = _lib.Context.get(dev)
 ctx.set_option("conv_dma", int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 model = bench.build_model(torch, dev, "bf16")
-for _ in range(45): model(x)
+for _ in range(4100): model(x)
 torch.cuda.synchronize()
