@@ -175,6 +175,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "time_split") == 0) { ctx->time_split = value; return DFA_OK; }
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "fuse_conv1") == 0) { ctx->fuse_conv1 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "lds_pipe") == 0) { ctx->lds_pipe = value ? 1 : 0; return DFA_OK; }

@@ -53,6 +53,7 @@ struct Cnn2dState {
   AugCfg train_aug{};                     // the augmentation of the forward_train in flight (its backward re-reads x through it)
   int train_prec = -1, train_B = 0, train_T = 0;
   int train_c1_fused = 0;                 // the forward left XX / Xs behind for the one-pass conv1 backward
+  int train_c1_mfma = 0;                  // this step's block-1 passes ran on train_conv1_mfma.hip
   int train_dgrad_m16 = 0;                // the d2/d3 images are in the 16x16x32 order of conv_split.hip (bf16 mode)
 };
 
@@ -97,6 +98,7 @@ struct dfa_ctx {
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
   int time_split = -1;         // eval forward, small batches: -1 = automatic time-axis split, 0 = off, n > 0 = force n segments
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
+  int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
@@ -236,13 +238,18 @@ hipError_t launch_bce_smooth(const float* logits, const float* labels, float eps
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                         float wd, int step, float grad_scale, hipStream_t s);
 int conv1_train_blocks(int B, int T, int F);
+// train_conv1_mfma.hip: the block-1 train passes on the matrix cores (bf16 features, no folded augmentation)
+enum { C1X_STATS = 0, C1X_FWD = 1, C1X_BWD = 2 };
+int conv1_mfma_blocks(int B, int T, int F);
+hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, int64_t sf, const float* w, const float* bias,
+                             void* a1, const void* da1, float* partial, int B, int T, int F, const DropCfg& dc, hipStream_t s);
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
                               int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1, const AugCfg* aug = nullptr);
 hipError_t launch_conv1_bwd_finalize(const float* rec, const float* xxs, const float* w, const float* bconv, const float* mean,
                                      const float* invstd, const float* gamma, double n, float* dw, float* db, float* dgamma,
-                                     float* dbeta, hipStream_t s);
+                                     float* dbeta, hipStream_t s, int derive_s2 = 0);
 // cae_train.hip
 hipError_t launch_pixel_unshuffle(int prec, const void* dz, void* zp, int B, int H, int W, int Wo, int C, hipStream_t s);
 hipError_t launch_convt_w_to_q(const float* w, float* wq, int cin, int cout, hipStream_t s);

@@ -50,6 +50,18 @@ __device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, floa
   }
 }
 
+// the same draw as drop_scale8 as AND-masks over packed bf16 pairs: km[j] covers elements 2j (low half) and 2j+1 (high half),
+// all ones where the element is kept
+__device__ __forceinline__ void drop_keep8(const DropCfg& d, uint64_t idx, unsigned* km) {
+  const uint64_t q = (idx >> 3) + d.offset;
+  const uint2 key = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
+  const uint4 r0 = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
+  const unsigned t16 = d.thresh >> 16;
+  const unsigned r[4] = {r0.x, r0.y, r0.z, r0.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) km[j] = (((r[j] & 0xffffu) < t16) ? 0u : 0x0000ffffu) | (((r[j] >> 16) < t16) ? 0u : 0xffff0000u);
+}
+
 // ---- train-time feature augmentation folded into the loads of the kernels that read x (src/train.py:68-69 applies
 // src/augmentation.py:5-186 to the batch before the model).  The augmented tensor is
 //   xa[b][t][f] = keep[f] * mask(x[b][(t - shift) mod T][f]) + std * N(0,1)(seed, offset + (b*T + t)*F + f)

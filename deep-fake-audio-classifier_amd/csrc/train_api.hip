@@ -174,7 +174,12 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   }
   const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
   m.train_c1_fused = ctx->conv1_bwd_fused ? 1 : 0;
-  const int nb1f = conv1_train_blocks(B, T, F);
+  // matrix-core passes: bf16 mode on bf16 features without a folded augmentation (its noise makes x non-bf16), fused backward
+  m.train_c1_mfma = (ctx->conv1_mfma && m.train_c1_fused && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && !aug && F <= 320) ? 1 : 0;
+  const int nb1f = m.train_c1_mfma ? conv1_mfma_blocks(B, T, F) : conv1_train_blocks(B, T, F);
+  if (m.train_c1_mfma)
+    DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_STATS, x, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, partial, B, T, F, dc, s));
+  else
   DFA_HIP_CHECK(ctx, launch_conv1_train(m.train_c1_fused ? C1M_STATS_XX : C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1],
                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prec, partial, B, T, F, dc, s, 1, aug));
   DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nb1f, 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, s));
@@ -184,6 +189,9 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   }
   DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], s1.mean, s1.var, m.tw1, m.tb1, 32, s));
   dc.layer = 1;
+  if (m.train_c1_mfma)
+    DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_FWD, x, stride_b, stride_t, stride_f, m.tw1, m.tb1, ws + pl.a1, nullptr, nullptr, B, T, F, dc, s));
+  else
   DFA_HIP_CHECK(ctx, launch_conv1(x, x_dtype, stride_b, stride_t, stride_f, m.tw1, m.tb1, ws + pl.a1, prec, B, T, F, s, &dc, aug));
   // ---- block 2
   const int nstrips = (F + 31) / 32;
@@ -272,6 +280,16 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   dc.layer = 1;
   const int nb1 = conv1_train_blocks(B, T, F);
   const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
+  if (m.train_c1_mfma && ctx->conv1_mfma) {   // (the option may be cleared between forward and backward: the vector kernel reads the same forward state -- twin test)
+    // the ReLU mask comes from the forward's own folded image (m.tw1 / m.tb1 are this step's); S2 is derived in the finalize
+    const int nbm = conv1_mfma_blocks(B, T, F);
+    DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_BWD, x, stride_b, stride_t, stride_f, m.tw1, m.tb1, nullptr, ws + pl.da1, partial, B, T, F, dc, s));
+    DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nbm, 352, 1.0f, c1rec, s, partial + (size_t)nbm * 352));
+    DFA_HIP_CHECK(ctx, launch_conv1_bwd_finalize(c1rec, c1rec + 352, p[0], p[1], s1.mean, s1.invstd, p[2], (double)B * T * F, grads[0], grads[1],
+                                                 grads[2], grads[3], s, 1));
+    DFA_HIP_CHECK(ctx, hipGetLastError());
+    return DFA_OK;
+  }
   if (m.train_c1_fused) {
     DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_FUSED, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
                                           nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug));

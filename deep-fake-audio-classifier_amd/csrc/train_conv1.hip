@@ -238,12 +238,19 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ rec, const f
                                           const float* __restrict__ w, const float* __restrict__ bconv,
                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                           const float* __restrict__ gamma, double n, float* __restrict__ dw,
-                                          float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                          float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                          int derive_s2) {
   const int i = threadIdx.x;          // 320 threads: (channel c, k) with k = 9 -> the bias / BN entries
   const int c = i / 10, k = i - c * 10;
   if (c >= 32) return;
-  const double S1 = rec[c * 11 + 9], S2 = rec[c * 11 + 10];
   const double is = invstd[c], mu = mean[c], ga = (double)gamma[c] * is;
+  const double S1 = rec[c * 11 + 9];
+  double S2 = rec[c * 11 + 10];
+  if (derive_s2) {   // train_conv1_mfma.hip: sum dy*xhat = is * (sum dy*z - mu*S1),  sum dy*z = b*S1 + sum_j w_j * A[c][j]
+    double dz = (double)bconv[c] * S1;
+    for (int j = 0; j < 9; ++j) dz += (double)w[c * 9 + j] * (double)rec[c * 11 + j];
+    S2 = is * (dz - mu * S1);
+  }
   if (k < 9) {
     const double Xs = xxs[81 + k];
     double zx = (double)bconv[c] * Xs;
@@ -262,9 +269,9 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ rec, const f
 
 hipError_t launch_conv1_bwd_finalize(const float* rec, const float* xxs, const float* w, const float* bconv, const float* mean,
                                      const float* invstd, const float* gamma, double n, float* dw, float* db, float* dgamma,
-                                     float* dbeta, hipStream_t s) {
+                                     float* dbeta, hipStream_t s, int derive_s2) {
   hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(320), 0, s, rec, xxs, w, bconv, mean, invstd, gamma, n, dw, db,
-                     dgamma, dbeta);
+                     dgamma, dbeta, derive_s2);
   return hipGetLastError();
 }
 

@@ -1,0 +1,349 @@
+// train_conv1_mfma.hip -- the three train-mode passes over the 1-channel first block of the CNN2D (src/model.py:15-19, as run
+// by src/train.py:71-76) on the matrix cores, bf16 features.  train_conv1.hip / conv1.hip do the same passes on the vector
+// ALU (9 + ~15 FMAs per pixel and channel: 0.30 + 0.31 + 0.74 ms at [256,321,180]); they stay for fp32, for fp32 feature
+// tensors and for batches with the augmentation folded in, and as the twins the GPU tests compare this file with.
+//
+// One im2col tile serves every matrix product.  A workgroup walks NT = 2 pooled rows (4 convolution rows) x all F columns per
+// step: the feature rows go to LDS once, then every pixel gets a 32-byte record  col[pixel] = {x taps 0..8, 1.0, 0 x 6}  (bf16;
+// all zeros outside the image, so such pixels drop out of every sum by themselves).
+//   product 1   y[32 ch x 32 px] = W[32 x 16] . col^T[16 x 32]     v_mfma_f32_32x32x16_bf16, W = hi + lo + lo2: three bf16 terms
+//               carry the fp32 weight exactly (three MFMAs, x is bf16: every product is exact, only the fp32 accumulation
+//               rounds -- with two terms 0.1 % of the bf16 a1 moved by an ulp against the fp32 kernels and the tiny-batch
+//               oracle test drifted); the bias rides on the 1.0 slot.  The X
+//               operand is one aligned ds_read_b128 of a pixel's record.  Result: lane = pixel, 16 channels in registers.
+//   product 2   G[16 taps x 16 ch] += col[32 px x 16]^T . dy[32 px x 16 ch]   v_mfma_f32_16x16x32_bf16, both operands fetched
+//               with ds_read_b64_tr_b16 (pixels-major tiles read as 8 consecutive pixels per lane).
+// Modes:
+//   STATS  raw weights: z = conv1(x) + b;  per-channel sum / sum of squares over all T rows (BatchNorm sees the odd last row),
+//          and XX = col^T col (product 2 with dy := col): the 9 x 9 tap moments and the tap sums the fused backward algebra
+//          needs (train_conv1.hip header) -- same records as conv1_train_kernel<STATS_XX>.
+//   FWD    BatchNorm-folded weights: y -> ReLU -> AvgPool2d((2,1)) -> Dropout -> a1 [B][Ho][F][32] bf16 (two 16-byte stores per
+//          lane after a half-wave exchange, as conv12_fused.hip).
+//   BWD    the same y (same operands, same MFMAs: the ReLU mask is the forward's, bit for bit); dy = mask * keep * da1 is exact
+//          in bf16 (the factor 0.5 * dropout scale is applied to the sums), so A[c][k] = sum dy * x_k and S1 = sum dy (the 1.0
+//          tap) are one product 2 per 32 pixels.  S2 = sum dy * xhat needs no pass of its own: xhat = is*(z - mu) and
+//          z = b + sum_k w_k x_k, so  sum dy*z = b*S1 + sum_k w_k A[c][k]  (conv1_bwd_finalize_kernel, derive_s2).
+#include "dfa_internal.h"
+#include "rng.h"
+
+namespace dfa {
+
+namespace {
+constexpr int NT = 2, NR = 2 * NT + 2, NCR = 2 * NT;   // pooled rows per step; feature rows / convolution rows in LDS
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x2_t lds_tr16(unsigned addr) {
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(size_t)addr));
+}
+__device__ __forceinline__ f32x16_t mma32(const uint4& w, const uint4& x, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mma16(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+}  // namespace
+
+struct C1xArgs {
+  const bf16_t* x;
+  int64_t sb, st, sf;
+  const float* w;       // [32][9]  raw (STATS) or BatchNorm-folded (FWD, BWD)
+  const float* b;       // [32]
+  bf16_t* a1;           // FWD: out [B][Ho][F][32]
+  const bf16_t* da1;    // BWD: in  [B][Ho][F][32]
+  float* partial;       // STATS: [nblk][32][2] then [nblk][96];  BWD: [nblk][32][11]
+  int T, F, Ho, FP, rows_per_wg;
+  float out_scale;      // BWD: 0.5 * dropout scale
+  DropCfg dc;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int i16 = lane & 15, q4 = lane >> 4, qrow = i16 >> 2, pq = i16 & 3;
+  const int T = a.T, F = a.F, FP = a.FP, NFC = FP >> 5, Ho = a.Ho;
+  const int RS = (FP + 2) * 2;                       // feature row in LDS: element i <-> f = i - 1
+  char* raw = smem;                                  // [NR][RS]
+  char* col = smem + ((NR * RS + 15) & ~15);         // [NCR][FP] x 32 bytes
+  char* dyt = col + NCR * FP * 32;                   // BWD: [4 waves][2 parities][32 px] x 64 bytes
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned col0 = lds0 + (unsigned)(col - smem), dyt0 = lds0 + (unsigned)(dyt - smem) + wave * 4096;
+  const int b = blockIdx.y;
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int NPm = (MODE == C1X_STATS) ? (T + 1) / 2 : Ho;
+  const int to_begin = blockIdx.x * a.rows_per_wg, to_end = min(NPm, to_begin + a.rows_per_wg);
+  const bf16_t* xb = a.x + (int64_t)b * a.sb;
+  const bool t_fast = (a.st == 1);
+
+  // A operand of product 1: lane (channel r, half h), element e <-> k = 8h + e: taps 0..8, bias at k = 9, zeros behind
+  uint4 whi, wlo, wl2;
+  {
+    unsigned hi[4], lo[4], l2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = 8 * h + 2 * j + u;
+        v[u] = (k < 9) ? a.w[r * 9 + k] : (k == 9 ? a.b[r] : 0.f);
+      }
+      const float h0 = bf16_to_float(float_to_bf16(v[0])), h1 = bf16_to_float(float_to_bf16(v[1]));
+      const float m0 = bf16_to_float(float_to_bf16(v[0] - h0)), m1 = bf16_to_float(float_to_bf16(v[1] - h1));
+      hi[j] = pack_bf16x2(v[0], v[1]);
+      lo[j] = pack_bf16x2(v[0] - h0, v[1] - h1);
+      l2[j] = pack_bf16x2((v[0] - h0) - m0, (v[1] - h1) - m1);      // three bf16 terms = the 24-bit mantissa: the fp32 weight, exactly
+    }
+    whi = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    wlo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    wl2 = make_uint4(l2[0], l2[1], l2[2], l2[3]);
+  }
+
+  float s1[16], s2[16];          // STATS: per-lane channel sums (channel (i&3) + 8*(i>>2) + 4h)
+  f32x4_t g2[2];                 // STATS: g2[0] = XX;  BWD: G for channels 0..15 / 16..31
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  g2[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  g2[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int to0 = to_begin; to0 < to_end; to0 += NT) {
+    __syncthreads();             // the previous step's readers are done
+    // ---- feature rows 2*to0-1 .. 2*to0+2*NT, columns -1 .. FP  (zeros outside the image = the convolution's padding)
+    for (int e = tid; e < NR * (FP + 2); e += 256) {
+      int rr, cc;
+      if (t_fast) { cc = e / NR; rr = e - cc * NR; } else { rr = e / (FP + 2); cc = e - rr * (FP + 2); }
+      const int t = 2 * to0 - 1 + rr, f = cc - 1;
+      unsigned short v = 0;
+      if (t >= 0 && t < T && f >= 0 && f < F) v = xb[(int64_t)t * a.st + (int64_t)f * a.sf].v;
+      *(unsigned short*)(raw + rr * RS + cc * 2) = v;
+    }
+    __syncthreads();
+    // ---- im2col records: pixel (convolution row tr, column fi) <- rows tr..tr+2, elements fi..fi+2 of the feature rows
+    for (int e = tid; e < NCR * FP; e += 256) {
+      const int tr = e / FP, fi = e - tr * FP;
+      const bool valid = fi < F && 2 * to0 + tr < T && to0 + (tr >> 1) < to_end;
+      unsigned long long q[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const char* rp = raw + (tr + dy) * RS + (fi & ~1) * 2;
+        const unsigned d0 = *(const unsigned*)rp, d1 = *(const unsigned*)(rp + 4);
+        q[dy] = ((((unsigned long long)d1) << 32) | d0) >> (16 * (fi & 1));
+      }
+      uint4 lo4, hi4;
+      lo4.x = (unsigned)q[0];
+      lo4.y = (unsigned)((q[0] >> 32) & 0xffffu) | ((unsigned)q[1] << 16);
+      lo4.z = (unsigned)(q[1] >> 16);
+      lo4.w = (unsigned)q[2];
+      hi4.x = (unsigned)((q[2] >> 32) & 0xffffu) | 0x3f800000u;      // tap 8, then 1.0
+      hi4.y = 0u; hi4.z = 0u; hi4.w = 0u;
+      if (!valid) { lo4 = make_uint4(0u, 0u, 0u, 0u); hi4 = lo4; }
+      *(uint4*)(col + (size_t)e * 32) = lo4;
+      *(uint4*)(col + (size_t)e * 32 + 16) = hi4;
+    }
+    __syncthreads();
+    // ---- tiles: (pooled row, 32-column chunk), round-robin over the four waves
+    for (int id = wave; id < NT * NFC; id += 4) {
+      const int tl = id / NFC, fc = id - tl * NFC;
+      const int to = to0 + tl;
+      if (to >= to_end) continue;
+      const int f0 = fc * 32;
+      const unsigned cbe = (unsigned)(((2 * tl) * FP + f0) * 32), cbo = cbe + (unsigned)(FP * 32);
+      const uint4 xe = *(const uint4*)(col + cbe + r * 32 + 16 * h), xo = *(const uint4*)(col + cbo + r * 32 + 16 * h);
+      f32x16_t ye, yo;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ye[i] = 0.f; yo[i] = 0.f; }
+      ye = mma32(wl2, xe, ye);         // smallest terms first
+      yo = mma32(wl2, xo, yo);
+      ye = mma32(wlo, xe, ye);
+      yo = mma32(wlo, xo, yo);
+      ye = mma32(whi, xe, ye);
+      yo = mma32(whi, xo, yo);
+      const unsigned tr_off = (unsigned)((8 * q4 + qrow) * 32 + pq * 8);     // product 2, col^T operand: pixel rows of 32 bytes
+
+      if constexpr (MODE == C1X_STATS) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s1[i] += ye[i];
+          s2[i] = fmaf(ye[i], ye[i], s2[i]);
+          s1[i] += yo[i];
+          s2[i] = fmaf(yo[i], yo[i], s2[i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const unsigned ad = col0 + (p ? cbo : cbe) + tr_off;
+          const u32x2_t t0 = lds_tr16(ad), t1 = lds_tr16(ad + 4 * 32);
+          const uint4 op = make_uint4(t0[0], t0[1], t1[0], t1[1]);
+          g2[0] = mma16(op, op, g2[0]);
+        }
+      } else if constexpr (MODE == C1X_FWD) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.5f * (fmaxf(ye[i], 0.f) + fmaxf(yo[i], 0.f));
+        const int f = f0 + r;
+        const size_t pix = ((size_t)b * Ho + to) * F + f;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {       // half-wave exchange: this lane ends with the 8 channels of octet g + h
+          float o[8];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * g + u]), __float_as_uint(v[4 * g + 4 + u]), false, false);
+            o[u] = __uint_as_float(sw[0]);
+            o[4 + u] = __uint_as_float(sw[1]);
+          }
+          const int oct = g + h;
+          if (a.dc.thresh != 0) {
+            float ds[8];
+            drop_scale8(a.dc, pix * 32 + oct * 8, ds);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] *= ds[u];
+          }
+          if (f < F)
+            *(uint4*)(a.a1 + pix * 32 + oct * 8) =
+                make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+      } else {
+        const int f = f0 + r;
+        const size_t pix = ((size_t)b * Ho + to) * F + f;
+        // upstream gradient of octets h and 2 + h (16 bytes each), dropout keep mask applied, then handed round so that
+        // dd[G][jj] holds channels 8G + 4h + 2jj, +1 -- the channel pairs of the accumulator registers 4G + 2jj, +1
+        unsigned dd[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const int oct = g + h;
+          uint4 du = make_uint4(0u, 0u, 0u, 0u);
+          if (f < F) du = *(const uint4*)(a.da1 + pix * 32 + oct * 8);
+          if (a.dc.thresh != 0) {
+            unsigned km[4];
+            drop_keep8(a.dc, pix * 32 + oct * 8, km);
+            du.x &= km[0]; du.y &= km[1]; du.z &= km[2]; du.w &= km[3];
+          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(du.x, du.z, false, false);   // (Y = dword jj, X = dword 2 + jj)
+          const auto s1 = __builtin_amdgcn_permlane32_swap(du.y, du.w, false, false);
+          dd[g][0] = s0[0]; dd[g + 1][0] = s0[1];
+          dd[g][1] = s1[0]; dd[g + 1][1] = s1[1];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          char* dst = dyt + wave * 4096 + p * 2048 + r * 64 + 8 * h;
+#pragma unroll
+          for (int G = 0; G < 4; ++G) {
+            unsigned o2[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const float y0 = p ? yo[4 * G + 2 * jj] : ye[4 * G + 2 * jj], y1 = p ? yo[4 * G + 2 * jj + 1] : ye[4 * G + 2 * jj + 1];
+              const unsigned m = (y0 > 0.f ? 0x0000ffffu : 0u) | (y1 > 0.f ? 0xffff0000u : 0u);
+              o2[jj] = dd[G][jj] & m;
+            }
+            *(uint2*)(dst + 16 * G) = make_uint2(o2[0], o2[1]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // this wave's own tile: LDS executes a wave's accesses in order
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const unsigned ad = col0 + (p ? cbo : cbe) + tr_off;
+          const u32x2_t t0 = lds_tr16(ad), t1 = lds_tr16(ad + 4 * 32);
+          const uint4 xt = make_uint4(t0[0], t0[1], t1[0], t1[1]);
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const unsigned bd = dyt0 + p * 2048 + (8 * q4 + qrow) * 64 + (16 * c2 + 4 * pq) * 2;
+            const u32x2_t u0 = lds_tr16(bd), u1 = lds_tr16(bd + 4 * 64);
+            g2[c2] = mma16(xt, make_uint4(u0[0], u0[1], u1[0], u1[1]), g2[c2]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();                            // the next tile's stores stay behind these reads
+      }
+    }
+  }
+
+  // ---- block records
+  __syncthreads();
+  float* red = (float*)smem;
+  if constexpr (MODE == C1X_STATS) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+        s1[i] += __shfl_xor(s1[i], off, 64);
+        s2[i] += __shfl_xor(s2[i], off, 64);
+      }
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ch = (i & 3) + 8 * (i >> 2) + 4 * h;
+        red[wave * 64 + ch * 2] = s1[i];
+        red[wave * 64 + ch * 2 + 1] = s2[i];
+      }
+    }
+    float* red2 = red + 256;                   // [4 waves][16 j][16 k]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red2[wave * 256 + (4 * q4 + e) * 16 + i16] = g2[0][e];
+    __syncthreads();
+    if (tid < 64) a.partial[blk * 64 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    if (tid < 90) {
+      const int j = tid < 81 ? tid / 9 : 9, k = tid < 81 ? tid - 9 * (tid / 9) : tid - 81;
+      const int o = j * 16 + k;
+      float* part2 = a.partial + (size_t)gridDim.x * gridDim.y * 64;
+      part2[blk * 96 + tid] = (red2[o] + red2[256 + o]) + (red2[512 + o] + red2[768 + o]);
+    }
+  } else if constexpr (MODE == C1X_BWD) {
+    // G[c2][e]: tap 4*q4 + e, channel 16*c2 + i16  ->  red[wave][channel][12 taps]
+    if (q4 < 3) {
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave * 384 + (16 * c2 + i16) * 12 + 4 * q4 + e] = g2[c2][e];
+    }
+    __syncthreads();
+    for (int e = tid; e < 352; e += 256) {
+      const int ch = e / 11, k = e - 11 * ch;
+      float v = 0.f;
+      if (k < 10) {
+        const int o = ch * 12 + k;
+        v = ((red[o] + red[384 + o]) + (red[768 + o] + red[1152 + o])) * a.out_scale;
+      }
+      a.partial[blk * 352 + e] = v;          // k = 10 (S2) is derived by conv1_bwd_finalize_kernel
+    }
+  }
+}
+
+int conv1_mfma_rows_per_wg(int B, int T, int F) {
+  const int nb_max = conv1_train_blocks(B, T, F) / B;      // the partial buffer is sized for that many records per utterance
+  const int np = (T + 1) / 2;
+  int rows = (np + nb_max - 1) / nb_max;
+  rows = (rows + NT - 1) / NT * NT;
+  return rows;
+}
+int conv1_mfma_blocks(int B, int T, int F) {
+  const int rows = conv1_mfma_rows_per_wg(B, T, F), np = (T + 1) / 2;
+  return B * ((np + rows - 1) / rows);
+}
+
+hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, int64_t sf, const float* w, const float* bias,
+                             void* a1, const void* da1, float* partial, int B, int T, int F, const DropCfg& dc, hipStream_t s) {
+  C1xArgs a{};
+  a.x = (const bf16_t*)x; a.sb = sb; a.st = st; a.sf = sf;
+  a.w = w; a.b = bias; a.a1 = (bf16_t*)a1; a.da1 = (const bf16_t*)da1; a.partial = partial;
+  a.T = T; a.F = F; a.Ho = T / 2; a.FP = (F + 31) / 32 * 32;
+  a.rows_per_wg = conv1_mfma_rows_per_wg(B, T, F);
+  a.dc = dc;
+  a.out_scale = 0.5f * (dc.thresh != 0 ? dc.scale : 1.0f);
+  const int np = (T + 1) / 2;
+  dim3 grid((np + a.rows_per_wg - 1) / a.rows_per_wg, B), block(256);
+  const size_t RS = (size_t)(a.FP + 2) * 2;
+  size_t lds = ((NR * RS + 15) & ~(size_t)15) + (size_t)NCR * a.FP * 32;
+  if (mode == C1X_BWD) lds += 4 * 4096;
+  if (lds < 8192) lds = 8192;                  // the block-record reduction reuses the front of the buffer
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (mode == C1X_STATS) hipLaunchKernelGGL(conv1_mfma_kernel<C1X_STATS>, grid, block, lds, s, a);
+  else if (mode == C1X_FWD) hipLaunchKernelGGL(conv1_mfma_kernel<C1X_FWD>, grid, block, lds, s, a);
+  else hipLaunchKernelGGL(conv1_mfma_kernel<C1X_BWD>, grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

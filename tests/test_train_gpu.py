@@ -521,3 +521,70 @@ def test_one_pass_conv1_backward_matches_two_pass_path(golden):
                             assert torch.equal(new[n], old[n]), n      # nothing else changes
     finally:
         ctx.set_option("conv1_bwd_fused", 1)
+
+
+def test_conv1_matrix_core_passes_match_vector_path(golden):
+    """Round 2: with bf16 features the three block-1 train passes (statistics, forward, fused backward) run on the matrix
+    cores (train_conv1_mfma.hip: im2col records in LDS, hi + lo bf16 weights, transposed-read weight-gradient product).
+    Checked against the vector-ALU kernels they replace, pass by pass (end to end the two paths differ by bf16 storage noise
+    like any two valid implementations -- the emulated-oracle test bounds that):
+      statistics  running mean / variance after one step agree to fp32 summation noise;
+      forward     a1 (first region of the train workspace) differs in < 0.2 % of its elements and by at most one bf16 ulp
+                  (three bf16 terms carry the fp32 weights exactly; what remains is fp32 accumulation order);
+      backward    on the SAME forward state (the option is cleared between two backward calls) every other gradient is
+                  bit-identical and dW1, dgamma1, dbeta1 agree to the fp32 cancellation noise of sums over B*T*F pixels
+                  (tools/gpu_conv1_mfma_probe.py: both kernels sit ~1e-3 from a float64 evaluation at [96,321,180]).
+    Golden size, ragged widths with odd / small T, a batch that uses the second reduction level; without and with dropout
+    (same Philox draw in both paths)."""
+    from dfa_amd import _lib
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import cnn2d_forward_train_raw, cnn2d_backward_raw
+    _, g = golden("cnn2d_train")
+    ctx = _lib.Context.get(torch.device("cuda"))
+    gen = torch.Generator().manual_seed(29)
+    cases = [(torch.from_numpy(g["ls0.x"]).transpose(1, 2), torch.from_numpy(g["ls0.y"])),
+             ((torch.randn(3, 65, 21, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0])),
+             ((torch.randn(5, 40, 16, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0, 0.0, 1.0])),
+             ((torch.randn(200, 180, 161, generator=gen) * 3.2 - 0.07).transpose(1, 2), (torch.rand(200, generator=gen) > 0.5).float())]
+
+    def forward(flag, x, drop):
+        ctx.set_option("conv1_mfma", flag)
+        torch.manual_seed(4)
+        model = CNN2D(in_features=x.shape[2], dropout=drop, precision="bf16").to("cuda").train()
+        model._drop_seed = 77
+        xb = x.to("cuda").to(torch.bfloat16)           # strided [B, T, F] view of [B, F, T] storage, as the loaders hand it over
+        logits, c, ws = cnn2d_forward_train_raw(model, xb)
+        B, T, F = x.shape
+        a1 = ws[: B * (T // 2) * F * 32 * 2].view(torch.bfloat16).clone()
+        return model, xb, logits, c, ws, a1
+
+    try:
+        for drop in (0.0, 0.2):
+            for x, y in cases:
+                tag = (drop, tuple(x.shape))
+                m0, _, _, _, _, a1_old = forward(0, x, drop)
+                m1, xb, logits, c, ws, a1_new = forward(1, x, drop)
+                for n in ("running_mean", "running_var"):
+                    old, new = getattr(m0.conv[1], n), getattr(m1.conv[1], n)
+                    assert float((new - old).abs().max()) <= 2e-5 * max(float(old.abs().max()), 1e-6), (n, tag)
+                an, ao = a1_new.float(), a1_old.float()
+                diff = (an - ao).abs()            # one bf16 ulp is 2^-8 relative at most (a ReLU input within 1e-6 of zero may land on either side)
+                assert bool((diff <= 2.0 ** -8 * torch.maximum(an, ao) + 1e-6).all()), tag
+                assert float((diff != 0).float().mean()) < 0.002, tag
+                dl = ((torch.sigmoid(logits) - y.to("cuda").view(-1, 1)) / x.shape[0]).contiguous()
+                names = [n for n, _ in m1.named_parameters()]
+                ga = [torch.zeros_like(p) for p in m1.parameters()]
+                gb = [torch.zeros_like(p) for p in m1.parameters()]
+                cnn2d_backward_raw(m1, xb, dl, ga, c, ws)
+                ctx.set_option("conv1_mfma", 0)
+                cnn2d_backward_raw(m1, xb, dl, gb, c, ws)
+                for n, a, b in zip(names, ga, gb):
+                    if n in ("conv.0.weight", "conv.1.weight", "conv.1.bias"):
+                        scale = max(float(b.abs().max()), 1e-9)
+                        assert float((a - b).abs().max()) <= 1e-2 * scale, (n, tag, float((a - b).abs().max()) / scale)
+                    elif n == "conv.0.bias":      # dz sums to zero over the batch: both kernels return rounding noise
+                        assert float(a.abs().max()) <= 1e-4 * float(gb[0].abs().max()) + 1e-6, (n, tag)
+                    else:
+                        assert torch.equal(a, b), (n, tag)
+    finally:
+        ctx.set_option("conv1_mfma", 1)

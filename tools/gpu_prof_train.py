@@ -8,7 +8,7 @@ g = torch.Generator().manual_seed(1)
 stored = torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07
 y = (torch.rand(256, generator=g) > 0.5).float().to(dev)
 torch.manual_seed(0)
-model = CNN2D(dropout=0.2, precision="bf16").to(dev)
+model = CNN2D(dropout=float(__import__("os").environ.get("DFA_PROF_DROPOUT", "0.2")), precision="bf16").to(dev)
 x = stored.to(dev, dtype=torch.bfloat16).transpose(1, 2)
 tr = NativeTrainer(model, label_smoothing=0.05)
 for _ in range(6): tr.step(x, y)
