@@ -49,6 +49,8 @@
 #include <type_traits>
 #include <utility>
 
+#include "rng.h"
+
 namespace dfa {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -116,6 +118,9 @@ struct ConvArgs {
   // adds them in the same order -- so logits do not depend on the batch size or on the split, bit for bit.
   int seg_iters, chunk_iters;
   size_t emb_seg_stride;
+  // conv_split.hip PLAIN_BF16 (data gradient of block 2): thresh != 0 zeroes the elements the forward's dropout layer dropped
+  // (same Philox draw, element index = output index) -- the keep mask of the pooled a1 applied where da1 is produced
+  DropCfg drop;
 };
 
 // chunk swizzle as a function of the pixel slot (column) only

@@ -197,8 +197,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         const f32x4_t* acc = r ? acc1 : acc0;
         const auto d0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1]), false, false);
         const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][2], acc[1][3]), false, false);
-        if (t0 + r < H && col < W)
-          *(uint4*)((bf16_t*)a.out + (((size_t)b * H + t0 + r) * W + col) * COUT + cb) = make_uint4(d0[0], d1[0], d0[1], d1[1]);
+        if (t0 + r < H && col < W) {
+          const size_t oi = (((size_t)b * H + t0 + r) * W + col) * COUT + cb;
+          uint4 o = make_uint4(d0[0], d1[0], d0[1], d1[1]);
+          if (a.drop.thresh != 0) {       // one Philox call per 16-byte store
+            unsigned km[4];
+            drop_keep8(a.drop, oi, km);
+            o.x &= km[0]; o.y &= km[1]; o.z &= km[2]; o.w &= km[3];
+          }
+          *(uint4*)((bf16_t*)a.out + oi) = o;
+        }
       }
     } else {
       // AvgPool2d((2,1)) over the row pair (the 1/2 is in the weights), split into hi + lo and stored as two bf16 planes of

@@ -175,7 +175,9 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
   m.train_c1_fused = ctx->conv1_bwd_fused ? 1 : 0;
   // matrix-core passes: bf16 mode on bf16 features without a folded augmentation (its noise makes x non-bf16), fused backward
-  m.train_c1_mfma = (ctx->conv1_mfma && m.train_c1_fused && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && !aug && F <= 320) ? 1 : 0;
+  // (the backward reads da1 with the dropout keep mask already applied by the 16x16x32 data-gradient kernel)
+  m.train_c1_mfma = (ctx->conv1_mfma && m.train_c1_fused && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && !aug && F <= 224 &&
+                     (dc.thresh == 0 || m.train_dgrad_m16)) ? 1 : 0;
   const int nb1f = m.train_c1_mfma ? conv1_mfma_blocks(B, T, F) : conv1_train_blocks(B, T, F);
   if (m.train_c1_mfma)
     DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_STATS, x, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, partial, B, T, F, dc, s));
@@ -273,6 +275,7 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
     ConvArgs a{};
     a.in = ws + pl.dz2; a.wpack = m.d2.wpack; a.bias = m.d2.bias; a.out = ws + pl.da1;
     a.B = B; a.H = pl.H1; a.W = F; a.COUT = 32; a.relu = 0; a.zero_page = ctx->zero_page;
+    if (m.train_c1_mfma) { a.drop = dc; a.drop.layer = 1; }   // keep mask of a1's dropout where da1 is produced (idempotent for the vector kernel)
     if (m.train_dgrad_m16) DFA_HIP_CHECK(ctx, launch_train_dgrad2_m16(a, s, train_conv_variant() != 0));
     else DFA_HIP_CHECK(ctx, launch_train_dgrad2(prec, a, s));
   }

@@ -11,17 +11,23 @@
 //               rounds -- with two terms 0.1 % of the bf16 a1 moved by an ulp against the fp32 kernels and the tiny-batch
 //               oracle test drifted); the bias rides on the 1.0 slot.  The X
 //               operand is one aligned ds_read_b128 of a pixel's record.  Result: lane = pixel, 16 channels in registers.
-//   product 2   G[16 taps x 16 ch] += col[32 px x 16]^T . dy[32 px x 16 ch]   v_mfma_f32_16x16x32_bf16, both operands fetched
-//               with ds_read_b64_tr_b16 (pixels-major tiles read as 8 consecutive pixels per lane).
+//               FWD takes it as y[ch][px] (lane = pixel, 16 channels in registers: the layout a1 is stored in); STATS and BWD swap
+//               the operands, y^T[px][ch] (lane = channel, 16 pixels in registers) -- per-channel sums then need no cross-lane
+//               work, and the masked upstream gradient is already the register image of product 2's B operand.
+//   product 2   G[taps x 32 ch] += col^T[taps x 16 px] . dy[16 px x 32 ch]   v_mfma_f32_32x32x16_bf16; the col^T operand comes from
+//               two ds_read_b64_tr_b16 (pixels-major records read as 4 + 4 pixels per lane for one tap), in the pixel order the
+//               accumulator registers of product 1 hold: k = 8h + e  <->  pixel 16j + 4h + (e & 3) + 8 (e >> 2).  Only 16 of the
+//               32 tap rows exist; rows 16..31 of G are never read.
 // Modes:
 //   STATS  raw weights: z = conv1(x) + b;  per-channel sum / sum of squares over all T rows (BatchNorm sees the odd last row),
-//          and XX = col^T col (product 2 with dy := col): the 9 x 9 tap moments and the tap sums the fused backward algebra
-//          needs (train_conv1.hip header) -- same records as conv1_train_kernel<STATS_XX>.
+//          and XX = col^T col (v_mfma_f32_16x16x32_bf16, both operands the same transposed read): the 9 x 9 tap moments and the
+//          tap sums the fused backward algebra needs (train_conv1.hip header) -- same records as conv1_train_kernel<STATS_XX>.
 //   FWD    BatchNorm-folded weights: y -> ReLU -> AvgPool2d((2,1)) -> Dropout -> a1 [B][Ho][F][32] bf16 (two 16-byte stores per
 //          lane after a half-wave exchange, as conv12_fused.hip).
-//   BWD    the same y (same operands, same MFMAs: the ReLU mask is the forward's, bit for bit); dy = mask * keep * da1 is exact
-//          in bf16 (the factor 0.5 * dropout scale is applied to the sums), so A[c][k] = sum dy * x_k and S1 = sum dy (the 1.0
-//          tap) are one product 2 per 32 pixels.  S2 = sum dy * xhat needs no pass of its own: xhat = is*(z - mu) and
+//   BWD    the same y (same operand registers: the forward's ReLU mask); dy = mask * da1 is exact in bf16 -- the dropout keep
+//          mask is applied where da1 is produced (conv_split.hip, ConvArgs::drop) and the factor 0.5 * dropout scale goes on the
+//          sums -- so A[c][k] = sum dy * x_k and S1 = sum dy (the 1.0 tap) are two product 2's per 32 pixels and row.  da1 is
+//          read as 2-byte elements (lane = channel: 64 contiguous bytes per 32 lanes).  S2 = sum dy * xhat needs no pass of its own: xhat = is*(z - mu) and
 //          z = b + sum_k w_k x_k, so  sum dy*z = b*S1 + sum_k w_k A[c][k]  (conv1_bwd_finalize_kernel, derive_s2).
 #include "dfa_internal.h"
 #include "rng.h"
@@ -69,9 +75,8 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
   const int RS = (FP + 2) * 2;                       // feature row in LDS: element i <-> f = i - 1
   char* raw = smem;                                  // [NR][RS]
   char* col = smem + ((NR * RS + 15) & ~15);         // [NCR][FP] x 32 bytes
-  char* dyt = col + NCR * FP * 32;                   // BWD: [4 waves][2 parities][32 px] x 64 bytes
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned col0 = lds0 + (unsigned)(col - smem), dyt0 = lds0 + (unsigned)(dyt - smem) + wave * 4096;
+  const unsigned col0 = lds0 + (unsigned)(col - smem);
   const int b = blockIdx.y;
   const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   const int NPm = (MODE == C1X_STATS) ? (T + 1) / 2 : Ho;
@@ -102,48 +107,95 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
     wl2 = make_uint4(l2[0], l2[1], l2[2], l2[3]);
   }
 
-  float s1[16], s2[16];          // STATS: per-lane channel sums (channel (i&3) + 8*(i>>2) + 4h)
-  f32x4_t g2[2];                 // STATS: g2[0] = XX;  BWD: G for channels 0..15 / 16..31
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t sa = {0.f, 0.f}, sq = {0.f, 0.f};   // STATS: this lane's channel r: sum / sum of squares (two interleaved partial sums)
+  f32x4_t gxx = {0.f, 0.f, 0.f, 0.f};         // STATS: XX
+  f32x16_t gw;                                // BWD: G[tap][channel r]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-  g2[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  g2[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 16; ++i) gw[i] = 0.f;
 
-  for (int to0 = to_begin; to0 < to_end; to0 += NT) {
-    __syncthreads();             // the previous step's readers are done
-    // ---- feature rows 2*to0-1 .. 2*to0+2*NT, columns -1 .. FP  (zeros outside the image = the convolution's padding)
-    for (int e = tid; e < NR * (FP + 2); e += 256) {
-      int rr, cc;
-      if (t_fast) { cc = e / NR; rr = e - cc * NR; } else { rr = e / (FP + 2); cc = e - rr * (FP + 2); }
-      const int t = 2 * to0 - 1 + rr, f = cc - 1;
+  // feature rows of a step -> registers (issued before the previous step's tiles are computed), then -> LDS.  Which element a
+  // thread moves does not depend on the step: its global offset, LDS offset and column validity are computed once.
+  constexpr int NXR = 6;                      // NR * (FP + 2) <= 6 * 256 elements: FP <= 254 (checked by the launcher)
+  unsigned short xr[NXR];
+  constexpr int64_t XG_NONE = INT64_MIN;      // (a real offset can be -1: row -1 of column 0)
+  int64_t xg[NXR];                            // element offset of (row rr, column f) relative to row 2*to0, or XG_NONE: never loaded
+  int xl[NXR], xrr[NXR];                      // LDS byte offset (-1: not this thread's), row rr
+#pragma unroll
+  for (int k = 0; k < NXR; ++k) {
+    const int e = k * 256 + tid;
+    int rr, cc;
+    if (t_fast) { cc = e / NR; rr = e - cc * NR; } else { rr = e / (FP + 2); cc = e - rr * (FP + 2); }
+    const int f = cc - 1;
+    const bool mine = e < NR * (FP + 2);
+    xrr[k] = rr;
+    xl[k] = mine ? rr * RS + cc * 2 : -1;
+    xg[k] = (mine && f >= 0 && f < F) ? (int64_t)(rr - 1) * a.st + (int64_t)f * a.sf : XG_NONE;
+  }
+  auto raw_load = [&](int to0) {
+    const bf16_t* xs = xb + (int64_t)(2 * to0) * a.st;
+#pragma unroll
+    for (int k = 0; k < NXR; ++k) {
+      const int t = 2 * to0 - 1 + xrr[k];
       unsigned short v = 0;
-      if (t >= 0 && t < T && f >= 0 && f < F) v = xb[(int64_t)t * a.st + (int64_t)f * a.sf].v;
-      *(unsigned short*)(raw + rr * RS + cc * 2) = v;
+      if (xg[k] != XG_NONE && t >= 0 && t < T) v = xs[xg[k]].v;
+      xr[k] = v;
     }
-    __syncthreads();
-    // ---- im2col records: pixel (convolution row tr, column fi) <- rows tr..tr+2, elements fi..fi+2 of the feature rows
-    for (int e = tid; e < NCR * FP; e += 256) {
-      const int tr = e / FP, fi = e - tr * FP;
-      const bool valid = fi < F && 2 * to0 + tr < T && to0 + (tr >> 1) < to_end;
+  };
+  auto raw_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < NXR; ++k)
+      if (xl[k] >= 0) *(unsigned short*)(raw + xl[k]) = xr[k];
+  };
+  // im2col: a thread's (up to two) pixel pairs, fixed over the steps
+  constexpr int NIC = 2;                      // NCR * FP / 2 <= 2 * 256 pairs: FP <= 256
+  int ic_src[NIC], ic_dst[NIC], ic_tr[NIC], ic_fi[NIC];
+#pragma unroll
+  for (int k = 0; k < NIC; ++k) {
+    const int e = k * 256 + tid;
+    const int tr = e / (FP >> 1), fi = 2 * (e - tr * (FP >> 1));
+    const bool mine = e < NCR * (FP >> 1);
+    ic_tr[k] = mine ? tr : -1;
+    ic_fi[k] = fi;
+    ic_src[k] = tr * RS + fi * 2;
+    ic_dst[k] = (tr * FP + fi) * 32;
+  }
+
+  if (to_begin < to_end) raw_load(to_begin);
+  for (int to0 = to_begin; to0 < to_end; to0 += NT) {
+    raw_store();                 // the previous step's im2col (the only reader of the feature rows) is behind its barrier
+    __syncthreads();             // feature rows complete; every wave is done with the previous step's records
+    // ---- im2col records, two adjacent pixels per thread: pixel (convolution row tr, column fi) <- rows tr..tr+2, elements
+    //      fi..fi+2 of the feature rows (element i <-> f = i - 1)
+#pragma unroll
+    for (int k = 0; k < NIC; ++k) {
+      const int tr = ic_tr[k], fi = ic_fi[k];
+      if (tr < 0) continue;
+      const bool row_ok = 2 * to0 + tr < T && to0 + (tr >> 1) < to_end;
       unsigned long long q[3];
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const char* rp = raw + (tr + dy) * RS + (fi & ~1) * 2;
-        const unsigned d0 = *(const unsigned*)rp, d1 = *(const unsigned*)(rp + 4);
-        q[dy] = ((((unsigned long long)d1) << 32) | d0) >> (16 * (fi & 1));
+        const unsigned* rp = (const unsigned*)(raw + ic_src[k] + dy * RS);
+        q[dy] = ((unsigned long long)rp[1] << 32) | rp[0];
       }
-      uint4 lo4, hi4;
-      lo4.x = (unsigned)q[0];
-      lo4.y = (unsigned)((q[0] >> 32) & 0xffffu) | ((unsigned)q[1] << 16);
-      lo4.z = (unsigned)(q[1] >> 16);
-      lo4.w = (unsigned)q[2];
-      hi4.x = (unsigned)((q[2] >> 32) & 0xffffu) | 0x3f800000u;      // tap 8, then 1.0
-      hi4.y = 0u; hi4.z = 0u; hi4.w = 0u;
-      if (!valid) { lo4 = make_uint4(0u, 0u, 0u, 0u); hi4 = lo4; }
-      *(uint4*)(col + (size_t)e * 32) = lo4;
-      *(uint4*)(col + (size_t)e * 32 + 16) = hi4;
+      char* dst = col + ic_dst[k];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned long long q0 = q[0] >> (16 * u), q1 = q[1] >> (16 * u), q2 = q[2] >> (16 * u);
+        uint4 lo4, hi4;
+        lo4.x = (unsigned)q0;
+        lo4.y = (unsigned)((q0 >> 32) & 0xffffu) | ((unsigned)q1 << 16);
+        lo4.z = (unsigned)(q1 >> 16);
+        lo4.w = (unsigned)q2;
+        hi4.x = (unsigned)((q2 >> 32) & 0xffffu) | 0x3f800000u;      // tap 8, then 1.0
+        hi4.y = 0u; hi4.z = 0u; hi4.w = 0u;
+        if (!(row_ok && fi + u < F)) { lo4 = make_uint4(0u, 0u, 0u, 0u); hi4 = lo4; }
+        *(uint4*)(dst + 32 * u) = lo4;
+        *(uint4*)(dst + 32 * u + 16) = hi4;
+      }
     }
     __syncthreads();
+    if (to0 + NT < to_end) raw_load(to0 + NT);      // in flight under the tiles
     // ---- tiles: (pooled row, 32-column chunk), round-robin over the four waves
     for (int id = wave; id < NT * NFC; id += 4) {
       const int tl = id / NFC, fc = id - tl * NFC;
@@ -155,28 +207,38 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
       f32x16_t ye, yo;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { ye[i] = 0.f; yo[i] = 0.f; }
-      ye = mma32(wl2, xe, ye);         // smallest terms first
-      yo = mma32(wl2, xo, yo);
-      ye = mma32(wlo, xe, ye);
-      yo = mma32(wlo, xo, yo);
-      ye = mma32(whi, xe, ye);
-      yo = mma32(whi, xo, yo);
-      const unsigned tr_off = (unsigned)((8 * q4 + qrow) * 32 + pq * 8);     // product 2, col^T operand: pixel rows of 32 bytes
+      if constexpr (MODE == C1X_FWD) {       // y[ch][px]: lane = pixel r, registers = channels (i&3) + 8*(i>>2) + 4h
+        ye = mma32(wl2, xe, ye);             // smallest terms first
+        yo = mma32(wl2, xo, yo);
+        ye = mma32(wlo, xe, ye);
+        yo = mma32(wlo, xo, yo);
+        ye = mma32(whi, xe, ye);
+        yo = mma32(whi, xo, yo);
+      } else {                               // y^T[px][ch]: lane = channel r, registers = pixels (i&3) + 8*(i>>2) + 4h
+        ye = mma32(xe, wl2, ye);
+        yo = mma32(xo, wl2, yo);
+        ye = mma32(xe, wlo, ye);
+        yo = mma32(xo, wlo, yo);
+        ye = mma32(xe, whi, ye);
+        yo = mma32(xo, whi, yo);
+      }
 
       if constexpr (MODE == C1X_STATS) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          s1[i] += ye[i];
-          s2[i] = fmaf(ye[i], ye[i], s2[i]);
-          s1[i] += yo[i];
-          s2[i] = fmaf(yo[i], yo[i], s2[i]);
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2_t ve = {ye[i], ye[i + 1]}, vo = {yo[i], yo[i + 1]};
+          sa += ve;
+          sq = __builtin_elementwise_fma(ve, ve, sq);
+          sa += vo;
+          sq = __builtin_elementwise_fma(vo, vo, sq);
         }
+        const unsigned tr_off = (unsigned)((8 * q4 + qrow) * 32 + pq * 8);     // 16 x 16 x 32: lane (tap i16, q4) <- pixels 8*q4 .. +7
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const unsigned ad = col0 + (p ? cbo : cbe) + tr_off;
           const u32x2_t t0 = lds_tr16(ad), t1 = lds_tr16(ad + 4 * 32);
           const uint4 op = make_uint4(t0[0], t0[1], t1[0], t1[1]);
-          g2[0] = mma16(op, op, g2[0]);
+          gxx = mma16(op, op, gxx);
         }
       } else if constexpr (MODE == C1X_FWD) {
         float v[16];
@@ -205,57 +267,31 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
                 make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
         }
       } else {
-        const int f = f0 + r;
-        const size_t pix = ((size_t)b * Ho + to) * F + f;
-        // upstream gradient of octets h and 2 + h (16 bytes each), dropout keep mask applied, then handed round so that
-        // dd[G][jj] holds channels 8G + 4h + 2jj, +1 -- the channel pairs of the accumulator registers 4G + 2jj, +1
-        unsigned dd[4][2];
+        // upstream gradient of channel r at this lane's 16 pixels.  Columns beyond F are clamped to a valid address: their im2col
+        // records are all zero (y = 0 -> mask off, taps = 0), whatever is read there drops out.
+        const bf16_t* drow = a.da1 + ((size_t)b * Ho + to) * F * 32 + r;
+        unsigned dpk[8];
 #pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          const int oct = g + h;
-          uint4 du = make_uint4(0u, 0u, 0u, 0u);
-          if (f < F) du = *(const uint4*)(a.da1 + pix * 32 + oct * 8);
-          if (a.dc.thresh != 0) {
-            unsigned km[4];
-            drop_keep8(a.dc, pix * 32 + oct * 8, km);
-            du.x &= km[0]; du.y &= km[1]; du.z &= km[2]; du.w &= km[3];
-          }
-          const auto s0 = __builtin_amdgcn_permlane32_swap(du.x, du.z, false, false);   // (Y = dword jj, X = dword 2 + jj)
-          const auto s1 = __builtin_amdgcn_permlane32_swap(du.y, du.w, false, false);
-          dd[g][0] = s0[0]; dd[g + 1][0] = s0[1];
-          dd[g][1] = s1[0]; dd[g + 1][1] = s1[1];
+        for (int i = 0; i < 16; i += 2) {
+          const int p0 = min(f0 + (i & 3) + 8 * (i >> 2) + 4 * h, F - 1), p1 = min(f0 + (i & 3) + 8 * (i >> 2) + 4 * h + 1, F - 1);
+          dpk[i >> 1] = (unsigned)drow[(size_t)p0 * 32].v | ((unsigned)drow[(size_t)p1 * 32].v << 16);
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          char* dst = dyt + wave * 4096 + p * 2048 + r * 64 + 8 * h;
+          const unsigned cb = col0 + (p ? cbo : cbe) + (unsigned)((4 * h + qrow) * 32 + pq * 8);
 #pragma unroll
-          for (int G = 0; G < 4; ++G) {
-            unsigned o2[2];
+          for (int j = 0; j < 2; ++j) {
+            unsigned dv[4];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-              const float y0 = p ? yo[4 * G + 2 * jj] : ye[4 * G + 2 * jj], y1 = p ? yo[4 * G + 2 * jj + 1] : ye[4 * G + 2 * jj + 1];
-              const unsigned m = (y0 > 0.f ? 0x0000ffffu : 0u) | (y1 > 0.f ? 0xffff0000u : 0u);
-              o2[jj] = dd[G][jj] & m;
+            for (int u = 0; u < 4; ++u) {
+              const float y0 = p ? yo[8 * j + 2 * u] : ye[8 * j + 2 * u], y1 = p ? yo[8 * j + 2 * u + 1] : ye[8 * j + 2 * u + 1];
+              dv[u] = (y0 > 0.f ? (dpk[4 * j + u] & 0x0000ffffu) : 0u) | (y1 > 0.f ? (dpk[4 * j + u] & 0xffff0000u) : 0u);
             }
-            *(uint2*)(dst + 16 * G) = make_uint2(o2[0], o2[1]);
+            // col^T for pixels 16j + 4h + {0..3} and 16j + 8 + 4h + {0..3}: the K order of the registers above
+            const u32x2_t t0 = lds_tr16(cb + (unsigned)(16 * j * 32)), t1 = lds_tr16(cb + (unsigned)((16 * j + 8) * 32));
+            gw = mma32(make_uint4(t0[0], t0[1], t1[0], t1[1]), make_uint4(dv[0], dv[1], dv[2], dv[3]), gw);
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // this wave's own tile: LDS executes a wave's accesses in order
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const unsigned ad = col0 + (p ? cbo : cbe) + tr_off;
-          const u32x2_t t0 = lds_tr16(ad), t1 = lds_tr16(ad + 4 * 32);
-          const uint4 xt = make_uint4(t0[0], t0[1], t1[0], t1[1]);
-#pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            const unsigned bd = dyt0 + p * 2048 + (8 * q4 + qrow) * 64 + (16 * c2 + 4 * pq) * 2;
-            const u32x2_t u0 = lds_tr16(bd), u1 = lds_tr16(bd + 4 * 64);
-            g2[c2] = mma16(xt, make_uint4(u0[0], u0[1], u1[0], u1[1]), g2[c2]);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();                            // the next tile's stores stay behind these reads
       }
     }
   }
@@ -264,25 +300,13 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
   __syncthreads();
   float* red = (float*)smem;
   if constexpr (MODE == C1X_STATS) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-#pragma unroll
-      for (int off = 1; off < 32; off <<= 1) {
-        s1[i] += __shfl_xor(s1[i], off, 64);
-        s2[i] += __shfl_xor(s2[i], off, 64);
-      }
-    }
-    if (r == 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ch = (i & 3) + 8 * (i >> 2) + 4 * h;
-        red[wave * 64 + ch * 2] = s1[i];
-        red[wave * 64 + ch * 2 + 1] = s2[i];
-      }
-    }
+    float s1v = sa[0] + sa[1], s2v = sq[0] + sq[1];
+    s1v += __shfl_xor(s1v, 32, 64);
+    s2v += __shfl_xor(s2v, 32, 64);
+    if (h == 0) { red[wave * 64 + r * 2] = s1v; red[wave * 64 + r * 2 + 1] = s2v; }
     float* red2 = red + 256;                   // [4 waves][16 j][16 k]
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red2[wave * 256 + (4 * q4 + e) * 16 + i16] = g2[0][e];
+    for (int e = 0; e < 4; ++e) red2[wave * 256 + (4 * q4 + e) * 16 + i16] = gxx[e];
     __syncthreads();
     if (tid < 64) a.partial[blk * 64 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
     if (tid < 90) {
@@ -292,12 +316,11 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
       part2[blk * 96 + tid] = (red2[o] + red2[256 + o]) + (red2[512 + o] + red2[768 + o]);
     }
   } else if constexpr (MODE == C1X_BWD) {
-    // G[c2][e]: tap 4*q4 + e, channel 16*c2 + i16  ->  red[wave][channel][12 taps]
-    if (q4 < 3) {
+    // gw[i]: tap (i&3) + 8*(i>>2) + 4h (i < 8: taps 0..15), channel r  ->  red[wave][channel][12 taps]
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave * 384 + (16 * c2 + i16) * 12 + 4 * q4 + e] = g2[c2][e];
+    for (int i = 0; i < 8; ++i) {
+      const int tap = (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (tap < 12) red[wave * 384 + r * 12 + tap] = gw[i];
     }
     __syncthreads();
     for (int e = tid; e < 352; e += 256) {
@@ -337,9 +360,8 @@ hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, in
   dim3 grid((np + a.rows_per_wg - 1) / a.rows_per_wg, B), block(256);
   const size_t RS = (size_t)(a.FP + 2) * 2;
   size_t lds = ((NR * RS + 15) & ~(size_t)15) + (size_t)NCR * a.FP * 32;
-  if (mode == C1X_BWD) lds += 4 * 4096;
   if (lds < 8192) lds = 8192;                  // the block-record reduction reuses the front of the buffer
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (lds > 64 * 1024 || NR * (a.FP + 2) > 6 * 256 || NCR * (a.FP / 2) > 2 * 256) return hipErrorInvalidValue;
   if (mode == C1X_STATS) hipLaunchKernelGGL(conv1_mfma_kernel<C1X_STATS>, grid, block, lds, s, a);
   else if (mode == C1X_FWD) hipLaunchKernelGGL(conv1_mfma_kernel<C1X_FWD>, grid, block, lds, s, a);
   else hipLaunchKernelGGL(conv1_mfma_kernel<C1X_BWD>, grid, block, lds, s, a);

@@ -532,8 +532,10 @@ def test_conv1_matrix_core_passes_match_vector_path(golden):
       forward     a1 (first region of the train workspace) differs in < 0.2 % of its elements and by at most one bf16 ulp
                   (three bf16 terms carry the fp32 weights exactly; what remains is fp32 accumulation order);
       backward    on the SAME forward state (the option is cleared between two backward calls) every other gradient is
-                  bit-identical and dW1, dgamma1, dbeta1 agree to the fp32 cancellation noise of sums over B*T*F pixels
-                  (tools/gpu_conv1_mfma_probe.py: both kernels sit ~1e-3 from a float64 evaluation at [96,321,180]).
+                  bit-identical and dW1, dgamma1, dbeta1 agree up to the handful of pixels whose pre-ReLU value is within fp32
+                  rounding of zero: the matrix-core kernel takes the mask from the forward's own folded weights, the vector
+                  kernel from gamma*xhat + beta (tools/gpu_conv1_mfma_probe.py: 1e-7 at [16,321,180], 3e-4 of dbeta1 -- three
+                  pixels' worth -- at [96,321,180], the same to all digits whatever the accumulation order).
     Golden size, ragged widths with odd / small T, a batch that uses the second reduction level; without and with dropout
     (same Philox draw in both paths)."""
     from dfa_amd import _lib
@@ -568,8 +570,8 @@ def test_conv1_matrix_core_passes_match_vector_path(golden):
                     old, new = getattr(m0.conv[1], n), getattr(m1.conv[1], n)
                     assert float((new - old).abs().max()) <= 2e-5 * max(float(old.abs().max()), 1e-6), (n, tag)
                 an, ao = a1_new.float(), a1_old.float()
-                diff = (an - ao).abs()            # one bf16 ulp is 2^-8 relative at most (a ReLU input within 1e-6 of zero may land on either side)
-                assert bool((diff <= 2.0 ** -8 * torch.maximum(an, ao) + 1e-6).all()), tag
+                diff = (an - ao).abs()            # one bf16 ulp is 2^-7 relative at most (a ReLU input within 1e-6 of zero may land on either side)
+                assert bool((diff <= 2.0 ** -7 * torch.maximum(an, ao) + 1e-6).all()), tag
                 assert float((diff != 0).float().mean()) < 0.002, tag
                 dl = ((torch.sigmoid(logits) - y.to("cuda").view(-1, 1)) / x.shape[0]).contiguous()
                 names = [n for n, _ in m1.named_parameters()]
