@@ -232,7 +232,7 @@ hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* 
 int bn_bwd_blocks(int B, int H, int W, int* pix_per_block);
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
-                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s);
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch = nullptr);
 hipError_t launch_bce_smooth(const float* logits, const float* labels, float eps, int B, float* loss, float* dlogits,
                              hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,

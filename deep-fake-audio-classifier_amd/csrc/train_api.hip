@@ -66,7 +66,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   size_t pb = (size_t)B * nstrips * 128 * 2 * 4;                              // conv stats partials
   pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 352 * 4);   // conv1 passes + 2nd-level scratch
   int ppb;
-  pb = std::max(pb, (size_t)bn_bwd_blocks(B, p.H1, F, &ppb) * 128 * 2 * 4);  // BN backward partials
+  pb = std::max(pb, ((size_t)bn_bwd_blocks(B, p.H1, F, &ppb) + 64) * 128 * 2 * 4);  // BN backward partials + 2nd-level scratch
   pb = std::max(pb, (size_t)kWgradWGs * ((size_t)128 * 64 * 9 + 256) * 4);   // weight-gradient partials
   pb = std::max(pb, ((size_t)B * F / 128 + 1) * 128 * 2 * 4);                // saved-sum BN reduction partials (8 * 16 positions per block)
   p.partial_bytes = pb;
@@ -267,8 +267,12 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   }
   // block 2
   dc.layer = 2;
-  DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL, ws + pl.z2, s2.mean, s2.invstd, p[8], p[9], nullptr, ws + pl.da2, partial, sm2, ws + pl.dz2,
-                                   B, pl.H1, F, 64, dc, s));
+  {
+    int ppb_;
+    float* scratch2 = partial + (size_t)bn_bwd_blocks(B, pl.H1, F, &ppb_) * 64 * 2;
+    DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL, ws + pl.z2, s2.mean, s2.invstd, p[8], p[9], nullptr, ws + pl.da2, partial, sm2, ws + pl.dz2,
+                                     B, pl.H1, F, 64, dc, s, scratch2));
+  }
   hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm2, grads[6], grads[7], 64);
   DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, 32, 64, ws + pl.dz2, ws + pl.a1, partial, grads[4], grads[5], B, pl.H1, F, kWgradWGs, s));
   {

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-// ---- SRC_POOL reduction on ROW PAIRS (H even): a thread takes a pooled pixel (to, f) x 8 channels -- ONE upstream load and ONE dropout
+// ---- SRC_POOL reduction and apply pass on ROW PAIRS (H even): a thread takes a pooled pixel (to, f) x 8 channels -- ONE upstream load and ONE dropout
 // draw serve the two rows 2*to, 2*to+1 of z that were averaged into it; several pooled pixels in flight per thread.  Same
 // per-element formulas as the generic kernel (which ran one dependent 16-byte load at a time: 3.0 TB/s).
 template <typename T>
@@ -553,6 +553,52 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
     float s = 0.f;
     for (int q = 0; q < PL; ++q) s += red[q * C * 2 + e];
     partial[(size_t)blockIdx.x * C * 2 + e] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ sums,
+                                                                const T* __restrict__ da, T* __restrict__ dz, int B, int H,
+                                                                int W, int C, DropCfg dc, float inv_n, int pp_per_block) {
+  const int CG = C >> 3, PL = 256 / CG, Ho = H >> 1;
+  const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+  const size_t npp = (size_t)B * Ho * W;
+  const size_t p0 = (size_t)blockIdx.x * pp_per_block;
+  const size_t p1 = (p0 + pp_per_block < npp) ? p0 + pp_per_block : npp;
+  float mu[8], is[8], gm[8], bt[8], k0[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c]; is[j] = invstd[c]; gm[j] = gamma[c]; bt[j] = beta[c];
+    k0[j] = gm[j] * is[j];
+    k1[j] = sums[2 * c] * inv_n;
+    k2[j] = sums[2 * c + 1] * inv_n;
+  }
+#pragma unroll 2
+  for (size_t pp = p0 + pl; pp < p1; pp += PL) {
+    const int f = (int)(pp % W);
+    const size_t bt_ = pp / W;
+    const int to = (int)(bt_ % Ho), b = (int)(bt_ / Ho);
+    const size_t zp = ((size_t)b * H + 2 * to) * W + f;
+    float v0[8], v1[8], d[8], ds[8], o0[8], o1[8];
+    ld8<T>(z + zp * C + cg * 8, v0);
+    ld8<T>(z + (zp + W) * C + cg * 8, v1);
+    ld8<T>(da + pp * C + cg * 8, d);
+    drop_scale8(dc, pp * C + cg * 8, ds);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float g = 0.5f * ds[j] * d[j];
+      const float xh0 = (v0[j] - mu[j]) * is[j], xh1 = (v1[j] - mu[j]) * is[j];
+      const float dy0 = (fmaf(gm[j], xh0, bt[j]) > 0.f) ? g : 0.f;
+      const float dy1 = (fmaf(gm[j], xh1, bt[j]) > 0.f) ? g : 0.f;
+      o0[j] = k0[j] * (dy0 - k1[j] - xh0 * k2[j]);
+      o1[j] = k0[j] * (dy1 - k1[j] - xh1 * k2[j]);
+    }
+    st8<T>(dz + zp * C + cg * 8, o0);
+    st8<T>(dz + (zp + W) * C + cg * 8, o1);
   }
 }
 
@@ -648,7 +694,7 @@ hipError_t launch_bn_finalize(const float* partial, int nparts, int C, double n,
 hipError_t launch_reduce_partials(const float* partial, int nparts, int n, float scale, float* out, hipStream_t s,
                                   float* scratch) {
   const int gx = (n + 31) / 32;
-  if (nparts <= 2048 || !scratch) {
+  if (nparts <= 256 || !scratch) {      // (a single level walks nparts / 8 records per thread: 83 us for 1800 records of 128 floats)
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, partial, nparts, n, scale, out, nparts);
     return hipGetLastError();
   }
@@ -775,10 +821,11 @@ int bn_bwd_blocks(int B, int H, int W, int* pix_per_block) {
   return (int)((npix + ppb - 1) / ppb);
 }
 
-// sums: [C][2] (S1 = dbeta, S2 = dgamma) written by the reduce stage; dz may alias nothing
+// sums: [C][2] (S1 = dbeta, S2 = dgamma) written by the reduce stage; dz may alias nothing.  scratch: 64 * C * 2 floats for the
+// two-level reduction of the block records (nullptr: one level)
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
-                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s) {
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch) {
   int ppb;
   const int nblk = bn_bwd_blocks(B, H, W, &ppb);
   const int PL = 256 / (C / 8);
@@ -794,11 +841,14 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
                        (const TT*)da, partial, B, H, W, C, dc, ppp);                                                   \
     hipError_t e = hipGetLastError();                                                                                  \
     if (e != hipSuccess) return e;                                                                                     \
-    e = launch_reduce_partials(partial, nb, C * 2, 1.0f, sums, s, nullptr);                                            \
+    e = launch_reduce_partials(partial, nb, C * 2, 1.0f, sums, s, scratch);                                            \
     if (e != hipSuccess) return e;                                                                                     \
-    if (dz) /* the row-pair form of the apply pass measured slower (0.435 vs 0.403 ms): the generic kernel stays */     \
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC_POOL>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \
-                         demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n, ppb2);                                   \
+    if (dz) {   /* 0.435 vs 0.475 ms for the generic kernel at [256,160,180,64] */                                      \
+      const int ppp2 = 8 * PL;                                                                                         \
+      dim3 g3((unsigned)(((size_t)B * (H / 2) * W + ppp2 - 1) / ppp2));                                                \
+      hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<TT>, g3, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \
+                         (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n, ppp2);                                         \
+    }                                                                                                                  \
   } while (0)
 #define DFA_BN_BWD(TT, SRC)                                                                                            \
   do {                                                                                                                 \
@@ -806,7 +856,7 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
                        beta, demb, (const TT*)da, partial, B, H, W, C, dc, ppb);                                       \
     hipError_t e = hipGetLastError();                                                                                  \
     if (e != hipSuccess) return e;                                                                                     \
-    e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s, nullptr);                                                   \
+    e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s, scratch);                                                     \
     if (e != hipSuccess) return e;                                                                                     \
     if (dz)                                                                                                            \
       hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \

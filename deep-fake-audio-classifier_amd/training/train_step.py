@@ -77,9 +77,8 @@ def cnn2d_forward_train_raw(model, x, update_running_stats=True):
         _lib.check(ctx.handle, code)
         model._train_gen = ctx.next_train_gen("cnn2d")
         model._train_shape = (B, T, F, prec, x.dtype)
-        if update_running_stats:
-            for i in model._BN_IDX:
-                model.conv[i].num_batches_tracked += 1
+        if update_running_stats:      # one multi-tensor launch instead of three
+            torch._foreach_add_([model.conv[i].num_batches_tracked for i in model._BN_IDX], 1)
     return logits, ctx, ws
 
 
