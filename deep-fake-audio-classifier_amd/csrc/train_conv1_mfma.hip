@@ -31,6 +31,7 @@
 //          z = b + sum_k w_k x_k, so  sum dy*z = b*S1 + sum_k w_k A[c][k]  (conv1_bwd_finalize_kernel, derive_s2).
 #include "dfa_internal.h"
 #include "rng.h"
+#include <stdlib.h>
 
 namespace dfa {
 
@@ -60,8 +61,9 @@ struct C1xArgs {
   const bf16_t* da1;    // BWD: in  [B][Ho][F][32]
   float* partial;       // STATS: [nblk][32][2] then [nblk][96];  BWD: [nblk][32][11]
   int T, F, Ho, FP, rows_per_wg;
-  float out_scale;      // BWD: 0.5 * dropout scale
+  float out_scale;      // 0.5 * dropout scale: FWD folds it into the weights, BWD applies it to the sums
   DropCfg dc;
+  int dbg;              // DFA_C1X_DBG (diagnostic): 1 = no tiles, 2 = no im2col, 4 = no feature-row traffic
 };
 
 template <int MODE>
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
       for (int u = 0; u < 2; ++u) {
         const int k = 8 * h + 2 * j + u;
         v[u] = (k < 9) ? a.w[r * 9 + k] : (k == 9 ? a.b[r] : 0.f);
+        if constexpr (MODE == C1X_FWD) v[u] *= a.out_scale;     // relu(s*y) = s*relu(y): the pool's 1/2 and the dropout scale ride on the weights
       }
       const float h0 = bf16_to_float(float_to_bf16(v[0])), h1 = bf16_to_float(float_to_bf16(v[1]));
       const float m0 = bf16_to_float(float_to_bf16(v[0] - h0)), m1 = bf16_to_float(float_to_bf16(v[1] - h1));
@@ -163,44 +166,51 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
 
   if (to_begin < to_end) raw_load(to_begin);
   for (int to0 = to_begin; to0 < to_end; to0 += NT) {
-    raw_store();                 // the previous step's im2col (the only reader of the feature rows) is behind its barrier
+    if (!(a.dbg & 4)) raw_store();                 // the previous step's im2col (the only reader of the feature rows) is behind its barrier
     __syncthreads();             // feature rows complete; every wave is done with the previous step's records
     // ---- im2col records, two adjacent pixels per thread: pixel (convolution row tr, column fi) <- rows tr..tr+2, elements
     //      fi..fi+2 of the feature rows (element i <-> f = i - 1)
 #pragma unroll
     for (int k = 0; k < NIC; ++k) {
       const int tr = ic_tr[k], fi = ic_fi[k];
-      if (tr < 0) continue;
+      if (tr < 0 || (a.dbg & 2)) continue;
       const bool row_ok = 2 * to0 + tr < T && to0 + (tr >> 1) < to_end;
-      unsigned long long q[3];
+      unsigned d0[3], d1[3];        // row dy: d0 = elements (fi, fi+1), d1 = (fi+2, fi+3); pixel fi uses fi..fi+2, pixel fi+1 uses fi+1..fi+3
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const unsigned* rp = (const unsigned*)(raw + ic_src[k] + dy * RS);
-        q[dy] = ((unsigned long long)rp[1] << 32) | rp[0];
+        d0[dy] = rp[0];
+        d1[dy] = rp[1];
       }
+      const unsigned m0[3] = {__builtin_amdgcn_alignbit(d1[0], d0[0], 16), __builtin_amdgcn_alignbit(d1[1], d0[1], 16),
+                              __builtin_amdgcn_alignbit(d1[2], d0[2], 16)};             // elements (fi+1, fi+2) of each row
+      const bool ok0 = row_ok && fi < F, ok1 = row_ok && fi + 1 < F;
+      // record = taps (row 0: 0 1 2)(row 1: 3 4 5)(row 2: 6 7 8), then 1.0, then zeros
+      uint4 a0, a1;
+      a0.x = d0[0];
+      a0.y = (d1[0] & 0xffffu) | (d0[1] << 16);
+      a0.z = m0[1];
+      a0.w = d0[2];
+      a1.x = m0[0];
+      a1.y = (d1[0] >> 16) | (m0[1] << 16);
+      a1.z = d1[1];
+      a1.w = m0[2];
+      unsigned t0 = (d1[2] & 0xffffu) | 0x3f800000u, t1 = (d1[2] >> 16) | 0x3f800000u;      // tap 8, then 1.0
+      if (!ok0) { a0 = make_uint4(0u, 0u, 0u, 0u); t0 = 0u; }
+      if (!ok1) { a1 = make_uint4(0u, 0u, 0u, 0u); t1 = 0u; }
       char* dst = col + ic_dst[k];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const unsigned long long q0 = q[0] >> (16 * u), q1 = q[1] >> (16 * u), q2 = q[2] >> (16 * u);
-        uint4 lo4, hi4;
-        lo4.x = (unsigned)q0;
-        lo4.y = (unsigned)((q0 >> 32) & 0xffffu) | ((unsigned)q1 << 16);
-        lo4.z = (unsigned)(q1 >> 16);
-        lo4.w = (unsigned)q2;
-        hi4.x = (unsigned)((q2 >> 32) & 0xffffu) | 0x3f800000u;      // tap 8, then 1.0
-        hi4.y = 0u; hi4.z = 0u; hi4.w = 0u;
-        if (!(row_ok && fi + u < F)) { lo4 = make_uint4(0u, 0u, 0u, 0u); hi4 = lo4; }
-        *(uint4*)(dst + 32 * u) = lo4;
-        *(uint4*)(dst + 32 * u + 16) = hi4;
-      }
+      *(uint4*)dst = a0;
+      *(uint4*)(dst + 16) = make_uint4(t0, 0u, 0u, 0u);
+      *(uint4*)(dst + 32) = a1;
+      *(uint4*)(dst + 48) = make_uint4(t1, 0u, 0u, 0u);
     }
     __syncthreads();
-    if (to0 + NT < to_end) raw_load(to0 + NT);      // in flight under the tiles
+    if (to0 + NT < to_end && !(a.dbg & 4)) raw_load(to0 + NT);      // in flight under the tiles
     // ---- tiles: (pooled row, 32-column chunk), round-robin over the four waves
     for (int id = wave; id < NT * NFC; id += 4) {
       const int tl = id / NFC, fc = id - tl * NFC;
       const int to = to0 + tl;
-      if (to >= to_end) continue;
+      if (to >= to_end || (a.dbg & 1)) continue;
       const int f0 = fc * 32;
       const unsigned cbe = (unsigned)(((2 * tl) * FP + f0) * 32), cbo = cbe + (unsigned)(FP * 32);
       const uint4 xe = *(const uint4*)(col + cbe + r * 32 + 16 * h), xo = *(const uint4*)(col + cbo + r * 32 + 16 * h);
@@ -241,30 +251,24 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
           gxx = mma16(op, op, gxx);
         }
       } else if constexpr (MODE == C1X_FWD) {
-        float v[16];
+        unsigned pk[8];               // pk[2G + jj]: channels 8G + 4h + 2jj, +1 (already scaled: see the weight operands)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = 0.5f * (fmaxf(ye[i], 0.f) + fmaxf(yo[i], 0.f));
+        for (int i = 0; i < 16; i += 2)
+          pk[i >> 1] = pack_bf16x2(fmaxf(ye[i], 0.f) + fmaxf(yo[i], 0.f), fmaxf(ye[i + 1], 0.f) + fmaxf(yo[i + 1], 0.f));
         const int f = f0 + r;
         const size_t pix = ((size_t)b * Ho + to) * F + f;
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {       // half-wave exchange: this lane ends with the 8 channels of octet g + h
-          float o[8];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * g + u]), __float_as_uint(v[4 * g + 4 + u]), false, false);
-            o[u] = __uint_as_float(sw[0]);
-            o[4 + u] = __uint_as_float(sw[1]);
-          }
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * g], pk[2 * g + 2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * g + 1], pk[2 * g + 3], false, false);
+          uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           const int oct = g + h;
-          if (a.dc.thresh != 0) {
-            float ds[8];
-            drop_scale8(a.dc, pix * 32 + oct * 8, ds);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o[u] *= ds[u];
+          if (a.dc.thresh != 0) {              // dropped elements -> 0 (the survivors' scale is in the weights)
+            unsigned km[4];
+            drop_keep8(a.dc, pix * 32 + oct * 8, km);
+            o.x &= km[0]; o.y &= km[1]; o.z &= km[2]; o.w &= km[3];
           }
-          if (f < F)
-            *(uint4*)(a.a1 + pix * 32 + oct * 8) =
-                make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+          if (f < F) *(uint4*)(a.a1 + pix * 32 + oct * 8) = o;
         }
       } else {
         // upstream gradient of channel r at this lane's 16 pixels.  Columns beyond F are clamped to a valid address: their im2col
@@ -336,6 +340,8 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
 }
 
 int conv1_mfma_rows_per_wg(int B, int T, int F) {
+  // 12 workgroups per utterance at F = 180 (3072 at B = 256: three rounds of 4 resident workgroups per CU).  One round of 4 long
+  // workgroups per utterance with the backward forced to 128 VGPRs measured slower (0.37 vs 0.22 ms: it spills).
   const int nb_max = conv1_train_blocks(B, T, F) / B;      // the partial buffer is sized for that many records per utterance
   const int np = (T + 1) / 2;
   int rows = (np + nb_max - 1) / nb_max;
@@ -355,6 +361,7 @@ hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, in
   a.T = T; a.F = F; a.Ho = T / 2; a.FP = (F + 31) / 32 * 32;
   a.rows_per_wg = conv1_mfma_rows_per_wg(B, T, F);
   a.dc = dc;
+  { static const char* e = getenv("DFA_C1X_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.out_scale = 0.5f * (dc.thresh != 0 ? dc.scale : 1.0f);
   const int np = (T + 1) / 2;
   dim3 grid((np + a.rows_per_wg - 1) / a.rows_per_wg, B), block(256);
