@@ -75,7 +75,13 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *   "block3_m16"    1 (default) = CNN2D bf16 block 3 on v_mfma_f32_16x16x32_bf16, 0 = the 32x32x16 kernel
  *   "time_split"    -1 (default) = CNN2D eval forward splits the time axis over workgroups when the batch alone cannot fill
  *                   the chip (B * strips below the resident-workgroup count, e.g. the reference's predict batch of 32), 0 =
- *                   never, n > 0 = force n segments (results agree to fp32 summation order of the time mean)
+ *                   never, n > 0 = force n segments (at most 4).  Logits and embeddings are bit-identical for every setting and
+ *                   batch size: the time mean is always summed in the same canonical chunks
+ *   "conv1_mfma"    1 (default) = bf16 training on bf16 features without a folded augmentation: the block-1 statistics,
+ *                   forward and fused backward passes run on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels.
+ *                   May be cleared between dfa_cnn2d_forward_train and dfa_cnn2d_backward (both backward kernels read the
+ *                   same forward state; used by the twin test)
+ *   "conv1_bwd_fused" 1 (default) = block-1 backward as one pass over da1 + algebra, 0 = reduce pass + weight-gradient pass
  *   "dgrad_m16"     1 (default) = bf16 training: each data-gradient convolution is ONE launch of the 16x16x32 kernel
  *                   (conv_split.hip), 0 = the 32x32x16 kernels (block 3 as two Cin-half launches through fp32 partial sums)
  *   "wgrad_variant" 3 (default) = pipelined bf16 weight-gradient kernel, 30 = its compiler-scheduled twin, 2 = the

@@ -23,6 +23,17 @@ ALGO = {   # algorithmic bytes per launch at B = 256, T = 321, F = 180 (DESIGN.m
     "conv_split_kernel<64, 2, 2": 256 * (160 * 180 * 64 * 2 + 160 * 180 * 32 * 2),    # train: dz2 in, da1 out
     "conv3_m16_meant_kernel<true, true>": 256 * (80 * 180 * 64 * 2 + 80 * 180 * 128 * 2),   # train forward 3: a2 in, z3 out
     "conv1_bn_relu_poolh2_kernel": 256 * (321 * 180 * 4 + 160 * 180 * 32 * 4),
+    "conv1_mfma_kernel<0>": 256 * (321 * 180 * 2),                                     # train statistics: x in
+    "conv1_mfma_kernel<1>": 256 * (321 * 180 * 2 + 160 * 180 * 32 * 2),               # train forward 1: x in, a1 out
+    "conv1_mfma_kernel<2>": 256 * (321 * 180 * 2 + 160 * 180 * 32 * 2),               # train backward 1: x, da1 in
+    "wgrad3x3_bf16_v3_kernel<64, 128": 256 * (80 * 180 * 128 * 2 + 80 * 180 * 64 * 2),     # dz3, a2 in
+    "wgrad3x3_bf16_v3_kernel<32, 64": 256 * (160 * 180 * 64 * 2 + 160 * 180 * 32 * 2),     # dz2, a1 in
+    "conv3x3_mfma_kernel<dfa::bf16_t, 32, 2, 2, 2, 1, 3": 256 * (160 * 180 * 32 * 2 + 160 * 180 * 64 * 2),   # train forward 2: a1 in, z2 out
+    "bn_relu_poolh2_drop_kernel": 256 * (160 * 180 * 64 * 2 + 80 * 180 * 64 * 2),
+    "bn_relu_meant_kernel": 256 * (80 * 180 * 128 * 2),
+    "bn_bwd_apply_meant_kernel": 256 * (80 * 180 * 128 * 2 * 2),
+    "bn_bwd_reduce_pool_kernel": 256 * (160 * 180 * 64 * 2 + 80 * 180 * 64 * 2),
+    "bn_bwd_apply_pool_kernel": 256 * (160 * 180 * 64 * 2 * 2 + 80 * 180 * 64 * 2),
 }
 
 if __name__ == "__main__":
