@@ -549,12 +549,14 @@ def test_conv1_matrix_core_passes_match_vector_path(golden):
              ((torch.randn(5, 40, 16, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0, 0.0, 1.0])),
              ((torch.randn(200, 180, 161, generator=gen) * 3.2 - 0.07).transpose(1, 2), (torch.rand(200, generator=gen) > 0.5).float())]
 
-    def forward(flag, x, drop):
+    def forward(flag, x, drop, contiguous=False):
         ctx.set_option("conv1_mfma", flag)
         torch.manual_seed(4)
         model = CNN2D(in_features=x.shape[2], dropout=drop, precision="bf16").to("cuda").train()
         model._drop_seed = 77
         xb = x.to("cuda").to(torch.bfloat16)           # strided [B, T, F] view of [B, F, T] storage, as the loaders hand it over
+        if contiguous:
+            xb = xb.contiguous()                       # [B, T, F] storage: the loaders' other stride pattern (stride_t = F, stride_f = 1)
         logits, c, ws = cnn2d_forward_train_raw(model, xb)
         B, T, F = x.shape
         a1 = ws[: B * (T // 2) * F * 32 * 2].view(torch.bfloat16).clone()
@@ -564,8 +566,9 @@ def test_conv1_matrix_core_passes_match_vector_path(golden):
         for drop in (0.0, 0.2):
             for x, y in cases:
                 tag = (drop, tuple(x.shape))
-                m0, _, _, _, _, a1_old = forward(0, x, drop)
-                m1, xb, logits, c, ws, a1_new = forward(1, x, drop)
+                contiguous = x.shape[0] == 5           # one case on [B, T, F] storage
+                m0, _, _, _, _, a1_old = forward(0, x, drop, contiguous)
+                m1, xb, logits, c, ws, a1_new = forward(1, x, drop, contiguous)
                 for n in ("running_mean", "running_var"):
                     old, new = getattr(m0.conv[1], n), getattr(m1.conv[1], n)
                     assert float((new - old).abs().max()) <= 2e-5 * max(float(old.abs().max()), 1e-6), (n, tag)
