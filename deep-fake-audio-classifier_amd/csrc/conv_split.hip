@@ -128,6 +128,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // PLAIN_BF16: the two output rows of an iteration wait in registers and are stored at the START of the next iteration, in
+  // front of its LDS-DMA loads: the iteration's closing vmcnt(0) (needed for the DMA before the barrier) counts stores too, and
+  // with the stores issued right before it every iteration paid a full write round trip
+  uint4 pend_o[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+  size_t pend_i[2] = {0, 0};
+  bool pend_ok[2] = {false, false};
+  auto flush_pending = [&]() {
+    if constexpr (EPI == SPLIT_EPI_PLAIN_BF16) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (pend_ok[r]) *(uint4*)((bf16_t*)a.out + pend_i[r]) = pend_o[r];
+    }
+  };
   auto unit = [&](auto ph_c, int it) {
     constexpr int PH = decltype(ph_c)::value;
     const int t0 = BR * it;
@@ -197,16 +210,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         const f32x4_t* acc = r ? acc1 : acc0;
         const auto d0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1]), false, false);
         const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][2], acc[1][3]), false, false);
-        if (t0 + r < H && col < W) {
-          const size_t oi = (((size_t)b * H + t0 + r) * W + col) * COUT + cb;
-          uint4 o = make_uint4(d0[0], d1[0], d0[1], d1[1]);
-          if (a.drop.thresh != 0) {       // one Philox call per 16-byte store
-            unsigned km[4];
-            drop_keep8(a.drop, oi, km);
-            o.x &= km[0]; o.y &= km[1]; o.z &= km[2]; o.w &= km[3];
-          }
-          *(uint4*)((bf16_t*)a.out + oi) = o;
+        const size_t oi = (((size_t)b * H + t0 + r) * W + col) * COUT + cb;
+        uint4 o = make_uint4(d0[0], d1[0], d0[1], d1[1]);
+        pend_ok[r] = t0 + r < H && col < W;
+        if (a.drop.thresh != 0 && pend_ok[r]) {       // one Philox call per 16-byte store
+          unsigned km[4];
+          drop_keep8(a.drop, oi, km);
+          o.x &= km[0]; o.y &= km[1]; o.z &= km[2]; o.w &= km[3];
         }
+        pend_o[r] = o;
+        pend_i[r] = oi;
       }
     } else {
       // AvgPool2d((2,1)) over the row pair (the 1/2 is in the weights), split into hi + lo and stored as two bf16 planes of
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
 
   auto iteration = [&](auto ph_c, int it) {
     constexpr int PH = decltype(ph_c)::value;
+    flush_pending();
     if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
     unit(ph_c, it);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     }
   }
 
+  flush_pending();               // the last iteration's rows
   if constexpr (EPI == SPLIT_EPI_MEAN_T) {
     if (a.seg_iters) return;     // split: the classifier kernel adds and scales the chunk sums
     // embedding rows [b][channel][col]: 16 consecutive columns per (channel, quarter-wave)

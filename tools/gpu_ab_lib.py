@@ -1,4 +1,5 @@
-"""A/B two builds of the library (separate processes, alternating): DFA_LIB=<file name under lib/>."""
+"""A/B two builds of the library (separate processes, alternating): DFA_LIB=<file name under lib/>; DFA_AB_MODE=train times the
+bf16 training step instead of the eval forward."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 from dfa_amd import _lib
@@ -6,6 +7,23 @@ name = os.environ.get("DFA_LIB")
 if name:
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), name)
 import bench
+if os.environ.get("DFA_AB_MODE") == "train":
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import NativeTrainer
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to(dev, dtype=torch.bfloat16).transpose(1, 2)
+    y = (torch.rand(256, generator=g) > 0.5).float().to(dev)
+    torch.manual_seed(0)
+    tr = NativeTrainer(CNN2D(dropout=0.2, precision="bf16").to(dev), label_smoothing=0.05)
+    for _ in range(5): tr.step(x, y)
+    res = []
+    for rnd in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): tr.step(x, y)
+        torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 10 * 1e3)
+    print(name, "train step ms median %.3f min %.3f" % (sorted(res)[2], min(res)), flush=True)
+    sys.exit(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(1234)
 x = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to(device=dev, dtype=torch.bfloat16).transpose(1, 2)
