@@ -26,9 +26,10 @@ if os.environ.get("DFA_AB_MODE") == "train":
     sys.exit(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(1234)
-x = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to(device=dev, dtype=torch.bfloat16).transpose(1, 2)
+PREC = os.environ.get("DFA_AB_PREC", "bf16")
+x = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to(device=dev, dtype=torch.bfloat16 if PREC == "bf16" else torch.float32).transpose(1, 2)
 ctx = _lib.Context.get(dev)
-model = bench.build_model(torch, dev, "bf16")
+model = bench.build_model(torch, dev, PREC)
 for _ in range(10): model(x)
 out = []
 for rnd in range(5):
