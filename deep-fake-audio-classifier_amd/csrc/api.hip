@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "dfa_internal.h"
+#include "trace.h"
 #include "convt2x2_mfma.h"
 
 using namespace dfa;
@@ -288,6 +289,7 @@ size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, i
 
 int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                       int64_t stride_f, float* logits, float* embedding, void* workspace, size_t workspace_bytes) {
+  TraceRange trace_("dfa_cnn2d_forward");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn2dState& m = ctx->cnn2d;
   if (m.prepared_prec < 0) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_prepare has not been called since the last set_params");
@@ -411,6 +413,7 @@ int dfa_cnn1d_prepare(dfa_ctx* ctx) {
 
 int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                       int64_t stride_f, float* logits, void* workspace, size_t workspace_bytes) {
+  TraceRange trace_("dfa_cnn1d_forward");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn1dState& m = ctx->cnn1d;
   if (!m.prepared) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_prepare has not been called since the last set_params");
@@ -498,6 +501,7 @@ int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
 int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                     int64_t stride_f, const float* mu, const float* sigma, float* recon, float* latent, float* mse,
                     void* workspace, size_t workspace_bytes) {
+  TraceRange trace_("dfa_cae_forward");
   if (!ctx) return DFA_E_NULL_PTR;
   CaeState& m = ctx->cae;
   if (m.prepared_prec < 0) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_prepare has not been called since the last set_params");

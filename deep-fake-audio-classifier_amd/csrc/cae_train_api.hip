@@ -2,6 +2,7 @@
 // over src/model_cae.py:32-125):  dfa_cae_forward_train (BatchNorm with batch statistics, running-stat update, keeps
 // what backward needs in the workspace) and dfa_cae_backward (gradients of the 30 parameters from d(loss)/d(recon)).
 #include "dfa_internal.h"
+#include "trace.h"
 #include "convt2x2_mfma.h"
 
 using namespace dfa;
@@ -113,6 +114,7 @@ size_t dfa_cae_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F, in
 int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                           int64_t stride_f, int precision, float momentum, int update_running_stats, float* recon,
                           float* latent, float* mse, void* workspace, size_t workspace_bytes) {
+  TraceRange trace_("dfa_cae_forward_train");
   if (!ctx) return DFA_E_NULL_PTR;
   CaeState& m = ctx->cae;
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_set_params has not been called");
@@ -211,6 +213,7 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
 int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                      int64_t stride_f, const float* drecon, float* const* grads, int ngrads, void* workspace,
                      size_t workspace_bytes) {
+  TraceRange trace_("dfa_cae_backward");
   if (!ctx) return DFA_E_NULL_PTR;
   CaeState& m = ctx->cae;
   if (!m.train_packed || m.train_B != B || m.train_T != T)

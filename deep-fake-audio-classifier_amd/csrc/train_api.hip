@@ -6,6 +6,7 @@
 //   dfa_bce_smooth_fwd_bwd  : BCEWithLogitsLoss(mean) on smoothed labels + dlogits      (src/train.py:311-320)
 //   dfa_adamw_step          : torch.optim.AdamW update of one flat fp32 buffer           (src/train.py:326-328)
 #include "dfa_internal.h"
+#include "trace.h"
 
 using namespace dfa;
 
@@ -101,6 +102,7 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
                             int64_t stride_t, int64_t stride_f, int precision, float p_drop, uint64_t seed,
                             uint64_t offset, float momentum, int update_running_stats, float* logits, float* embedding,
                             void* workspace, size_t workspace_bytes) {
+  TraceRange trace_("dfa_cnn2d_forward_train");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn2dState& m = ctx->cnn2d;
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_set_params has not been called");
@@ -231,6 +233,7 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
 int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                        int64_t stride_f, const float* dlogits, float* const* grads, int ngrads, void* workspace,
                        size_t workspace_bytes) {
+  TraceRange trace_("dfa_cnn2d_backward");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn2dState& m = ctx->cnn2d;
   if (!m.train_packed || m.train_B != B || m.train_T != T)
@@ -353,6 +356,7 @@ int dfa_bce_smooth_fwd_bwd(dfa_ctx* ctx, const float* logits, const float* label
 
 int dfa_adamw_step(dfa_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+  TraceRange trace_("dfa_adamw_step");
   if (!ctx) return DFA_E_NULL_PTR;
   if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(ctx, DFA_E_NULL_PTR, "adamw buffers must be non-null");
   if (step < 1) return fail(ctx, DFA_E_BAD_SHAPE, "step is 1-based (got %d)", step);
@@ -418,6 +422,7 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
                             int64_t stride_t, int64_t stride_f, float p_drop, uint64_t seed, uint64_t offset,
                             float momentum, int update_running_stats, float* logits, void* workspace,
                             size_t workspace_bytes) {
+  TraceRange trace_("dfa_cnn1d_forward_train");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn1dState& m = ctx->cnn1d;
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_set_params has not been called");
@@ -478,6 +483,7 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
 int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                        int64_t stride_f, const float* dlogits, float* const* grads, int ngrads, void* workspace,
                        size_t workspace_bytes) {
+  TraceRange trace_("dfa_cnn1d_backward");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn1dState& m = ctx->cnn1d;
   if (!m.train_packed || m.train_B != B || m.train_T != T)

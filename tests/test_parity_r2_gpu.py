@@ -394,3 +394,33 @@ def test_time_axis_split_is_bit_invariant(golden, prec):
             np.testing.assert_allclose(got, want, atol=TOL_BF16_EMU_REL * max(1.0, float(np.abs(want).max())), rtol=0)
     finally:
         ctx.set_option("time_split", -1)
+
+
+# ------------------------------------------------------------------------------------------------ tracing hook
+def test_roctx_ranges_do_not_change_results(golden):
+    """DFA_ROCTX=1 makes every C-ABI forward / backward / optimiser call push a named roctx range (csrc/trace.hip; the marker
+    library is dlopen'ed, no tool attached here so the ranges go nowhere).  The child process must load the marker library,
+    run the forward and reproduce this process's logits bit for bit."""
+    import subprocess, sys, os, tempfile
+    sd, g = golden("cnn2d_eval")
+    model = _model_from_sd(sd, "bf16")
+    x = torch.from_numpy(g["t321.x_stored"]).to("cuda").transpose(1, 2)
+    want = model(x).cpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        torch.save({"sd": {k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}, "x": torch.from_numpy(g["t321.x_stored"])},
+                   os.path.join(d, "in.pt"))
+        code = (
+            "import sys, torch; sys.path.insert(0, %r)\n"
+            "from dfa_amd.model import CNN2D\n"
+            "blob = torch.load(%r)\n"
+            "m = CNN2D(in_features=180, precision='bf16'); m.load_state_dict(blob['sd']); m = m.to('cuda').eval()\n"
+            "out = m(blob['x'].to('cuda').transpose(1, 2)).cpu()\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert 'roctx' in maps, 'marker library not loaded'\n"
+            "torch.save(out, %r)\n" % (root, os.path.join(d, "in.pt"), os.path.join(d, "out.pt")))
+        env = dict(os.environ, DFA_ROCTX="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = torch.load(os.path.join(d, "out.pt"))
+    assert torch.equal(got, want)
