@@ -547,6 +547,7 @@ def test_conv1_matrix_core_passes_match_vector_path(golden):
     cases = [(torch.from_numpy(g["ls0.x"]).transpose(1, 2), torch.from_numpy(g["ls0.y"])),
              ((torch.randn(3, 65, 21, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0])),
              ((torch.randn(5, 40, 16, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([0.0, 1.0, 1.0, 0.0, 1.0])),
+             ((torch.randn(2, 33, 5, generator=gen) * 3.2 - 0.07).transpose(1, 2), torch.tensor([1.0, 0.0])),      # smallest odd T, odd F
              ((torch.randn(200, 180, 161, generator=gen) * 3.2 - 0.07).transpose(1, 2), (torch.rand(200, generator=gen) > 0.5).float())]
 
     def forward(flag, x, drop, contiguous=False):
