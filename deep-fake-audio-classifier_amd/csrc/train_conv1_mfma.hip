@@ -4,7 +4,7 @@
 // tensors and for batches with the augmentation folded in, and as the twins the GPU tests compare this file with.
 //
 // One im2col tile serves every matrix product.  A workgroup walks NT = 2 pooled rows (4 convolution rows) x all F columns per
-// step: the feature rows go to LDS once, then every pixel gets a 32-byte record  col[pixel] = {x taps 0..8, 1.0, 0 x 6}  (bf16;
+// step: the feature rows go to LDS once, then every pixel gets a 32-byte record  col[pixel] = {x taps 0..8, 1.0, 0 x 6}  (bf16, two records per 80-byte slot;
 // all zeros outside the image, so such pixels drop out of every sum by themselves).
 //   product 1   y[32 ch x 32 px] = W[32 x 16] . col^T[16 x 32]     v_mfma_f32_32x32x16_bf16, W = hi + lo + lo2: three bf16 terms
 //               carry the fp32 weight exactly (three MFMAs, x is bf16: every product is exact, only the fp32 accumulation
@@ -52,6 +52,13 @@ __device__ __forceinline__ f32x4_t mma16(const uint4& a, const uint4& b, f32x4_t
 }
 }  // namespace
 
+// bytes per feature row in LDS: (FP + 2) bf16, padded to 3 (mod 32) dwords -- the 32 lanes of a ds_write_b16 group hold (row
+// 0..5, column pair) combinations, which then fall on distinct banks
+__host__ __device__ inline int c1x_row_bytes(int FP) {
+  const int d = (FP + 2) / 2;
+  return 4 * (d + (((3 - d) % 32) + 32) % 32);
+}
+
 struct C1xArgs {
   const bf16_t* x;
   int64_t sb, st, sf;
@@ -74,9 +81,13 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
   const int r = lane & 31, h = lane >> 5;
   const int i16 = lane & 15, q4 = lane >> 4, qrow = i16 >> 2, pq = i16 & 3;
   const int T = a.T, F = a.F, FP = a.FP, NFC = FP >> 5, Ho = a.Ho;
-  const int RS = (FP + 2) * 2;                       // feature row in LDS: element i <-> f = i - 1
+  const int RS = c1x_row_bytes(FP);                  // feature row in LDS: element i <-> f = i - 1
   char* raw = smem;                                  // [NR][RS]
-  char* col = smem + ((NR * RS + 15) & ~15);         // [NCR][FP] x 32 bytes
+  // im2col records: a PAIR of adjacent pixels takes an 80-byte slot (2 x 32 bytes + 16 of padding): the pair's thread writes
+  // its four 16-byte pieces with ds_write_b128, whose 8-lane groups then fall on disjoint banks (at the dense 64-byte pitch they
+  // were 4-way conflicted: 75 % of the LDS cycles of these kernels were conflict cycles, SQ_LDS_BANK_CONFLICT)
+  const int ROWB = FP * 40;                          // bytes per convolution row of records
+  char* col = smem + ((NR * RS + 15) & ~15);         // [NCR][FP / 2] x 80 bytes
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned col0 = lds0 + (unsigned)(col - smem);
   const int b = blockIdx.y;
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
     ic_tr[k] = mine ? tr : -1;
     ic_fi[k] = fi;
     ic_src[k] = tr * RS + fi * 2;
-    ic_dst[k] = (tr * FP + fi) * 32;
+    ic_dst[k] = tr * ROWB + (fi >> 1) * 80;
   }
 
   if (to_begin < to_end) raw_load(to_begin);
@@ -212,8 +223,9 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
       const int to = to0 + tl;
       if (to >= to_end || (a.dbg & 1)) continue;
       const int f0 = fc * 32;
-      const unsigned cbe = (unsigned)(((2 * tl) * FP + f0) * 32), cbo = cbe + (unsigned)(FP * 32);
-      const uint4 xe = *(const uint4*)(col + cbe + r * 32 + 16 * h), xo = *(const uint4*)(col + cbo + r * 32 + 16 * h);
+      const unsigned cbe = (unsigned)((2 * tl) * ROWB + f0 * 40), cbo = cbe + (unsigned)ROWB;
+      const unsigned xoff = (unsigned)((r >> 1) * 80 + (r & 1) * 32 + 16 * h);
+      const uint4 xe = *(const uint4*)(col + cbe + xoff), xo = *(const uint4*)(col + cbo + xoff);
       f32x16_t ye, yo;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { ye[i] = 0.f; yo[i] = 0.f; }
@@ -242,11 +254,12 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
           sa += vo;
           sq = __builtin_elementwise_fma(vo, vo, sq);
         }
-        const unsigned tr_off = (unsigned)((8 * q4 + qrow) * 32 + pq * 8);     // 16 x 16 x 32: lane (tap i16, q4) <- pixels 8*q4 .. +7
+        const int px = 8 * q4 + qrow;                                          // 16 x 16 x 32: lane (tap i16, q4) <- pixels 8*q4 .. +7
+        const unsigned tr_off = (unsigned)((px >> 1) * 80 + (px & 1) * 32 + pq * 8);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const unsigned ad = col0 + (p ? cbo : cbe) + tr_off;
-          const u32x2_t t0 = lds_tr16(ad), t1 = lds_tr16(ad + 4 * 32);
+          const u32x2_t t0 = lds_tr16(ad), t1 = lds_tr16(ad + 160);          // + 4 pixels = 2 pair slots
           const uint4 op = make_uint4(t0[0], t0[1], t1[0], t1[1]);
           gxx = mma16(op, op, gxx);
         }
@@ -282,7 +295,8 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const unsigned cb = col0 + (p ? cbo : cbe) + (unsigned)((4 * h + qrow) * 32 + pq * 8);
+          const int px = 4 * h + qrow;
+          const unsigned cb = col0 + (p ? cbo : cbe) + (unsigned)((px >> 1) * 80 + (px & 1) * 32 + pq * 8);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             unsigned dv[4];
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
               dv[u] = (y0 > 0.f ? (dpk[4 * j + u] & 0x0000ffffu) : 0u) | (y1 > 0.f ? (dpk[4 * j + u] & 0xffff0000u) : 0u);
             }
             // col^T for pixels 16j + 4h + {0..3} and 16j + 8 + 4h + {0..3}: the K order of the registers above
-            const u32x2_t t0 = lds_tr16(cb + (unsigned)(16 * j * 32)), t1 = lds_tr16(cb + (unsigned)((16 * j + 8) * 32));
+            const u32x2_t t0 = lds_tr16(cb + (unsigned)(16 * j * 40)), t1 = lds_tr16(cb + (unsigned)((16 * j + 8) * 40));
             gw = mma32(make_uint4(t0[0], t0[1], t1[0], t1[1]), make_uint4(dv[0], dv[1], dv[2], dv[3]), gw);
           }
         }
@@ -365,8 +379,8 @@ hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, in
   a.out_scale = 0.5f * (dc.thresh != 0 ? dc.scale : 1.0f);
   const int np = (T + 1) / 2;
   dim3 grid((np + a.rows_per_wg - 1) / a.rows_per_wg, B), block(256);
-  const size_t RS = (size_t)(a.FP + 2) * 2;
-  size_t lds = ((NR * RS + 15) & ~(size_t)15) + (size_t)NCR * a.FP * 32;
+  const size_t RS = (size_t)c1x_row_bytes(a.FP);
+  size_t lds = ((NR * RS + 15) & ~(size_t)15) + (size_t)NCR * a.FP * 40;
   if (lds < 8192) lds = 8192;                  // the block-record reduction reuses the front of the buffer
   if (lds > 64 * 1024 || NR * (a.FP + 2) > 6 * 256 || NCR * (a.FP / 2) > 2 * 256) return hipErrorInvalidValue;
   if (mode == C1X_STATS) hipLaunchKernelGGL(conv1_mfma_kernel<C1X_STATS>, grid, block, lds, s, a);
