@@ -594,3 +594,33 @@ def test_conv1_matrix_core_passes_match_vector_path(golden):
                         assert torch.equal(a, b), (n, tag)
     finally:
         ctx.set_option("conv1_mfma", 1)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_full_size_train_steps_are_bit_reproducible(prec):
+    """Size-independent property at BASELINE's full batch [256, 321, 180]: every reduction of the training step runs in a fixed
+    order (per-workgroup partial records + fixed-order second stages, no atomics), so three optimisation steps from the same
+    initial state, on the same batch with the same dropout key, must give bit-identical losses, gradients and parameters in
+    two independent runs -- a race between workgroups or waves would show up here as a difference."""
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import NativeTrainer
+    B = 256 if prec == "bf16" else 64          # (fp32: the same kernels' fp32 instantiations at a quarter of the batch)
+    gen = torch.Generator().manual_seed(31)
+    x = (torch.randn(B, 180, 321, generator=gen) * 3.2 - 0.07).to("cuda")
+    x = (x.to(torch.bfloat16) if prec == "bf16" else x).transpose(1, 2)
+    y = (torch.rand(B, generator=gen) > 0.5).float().to("cuda")
+
+    def run():
+        torch.manual_seed(5)
+        model = CNN2D(in_features=180, dropout=0.2, precision=prec).to("cuda")
+        model._drop_seed = 1234
+        tr = NativeTrainer(model, lr=1e-3, label_smoothing=0.05)
+        losses = []
+        for _ in range(3):
+            losses.append(tr.step(x, y).clone())
+        return torch.cat(losses), tr.flat_g.clone(), tr.flat_p.clone(), model.conv[1].running_var.clone()
+
+    a, b = run(), run()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[2]).all()
