@@ -228,3 +228,27 @@ def test_emulated_cae_oracle_without_rounding_equals_reference(golden):
         r16, l16 = R.cae_forward_emulated(sd, x, emulate="bf16")
         d = float((r16 - recon).abs().max())
         assert 1e-5 < d < 0.08, d
+
+
+def test_emulated_cae_training_oracle_without_rounding_equals_reference_autograd(golden):
+    """oracle.torch_ref.cae_train_step_emulated(emulate=None) -- the float64 autograd restatement behind the auto-encoder's bf16
+    training oracle -- reproduces the reference's own loss and per-parameter gradients (tests/golden/cae_train.npz, written by
+    src/model_cae.py under torch autograd); with the roundings on it moves by bf16 storage noise, not more."""
+    import torch
+    from oracle import torch_ref as R
+    _, g = golden("cae_train")
+    sd = {k[len("init.sd."):]: v for k, v in g.items() if k.startswith("init.sd.")}
+    x = torch.from_numpy(g["ls0.x"])
+    noise = {f"encoder.{i}.bias" for i in (0, 4, 8, 12)} | {f"decoder.{i}.bias" for i in (0, 3, 6)}   # bias before BatchNorm: zero gradient
+    loss, grads = R.cae_train_step_emulated(sd, x, emulate=None)
+    np.testing.assert_allclose(loss, g["ls0.loss"], rtol=1e-5)
+    for name, got in grads.items():
+        if name in noise:
+            continue
+        want = g["ls0.grad." + name]
+        scale = max(np.abs(want).max(), 1e-6)
+        np.testing.assert_allclose(got.numpy(), want, atol=1e-4 * scale + 1e-8, rtol=0, err_msg=name)
+    loss16, g16 = R.cae_train_step_emulated(sd, x, emulate="bf16")
+    assert abs(loss16 - loss) < 1e-3 * abs(loss)
+    rel = max(float((g16[n] - grads[n]).abs().max() / max(float(grads[n].abs().max()), 1e-6)) for n in grads if n not in noise)
+    assert 1e-4 < rel < 0.5, rel

@@ -377,36 +377,45 @@ def test_cae_train_step_matches_reference(golden):
 
 def test_cae_bf16_training_gradients_track_the_reference(golden):
     """bf16 storage mode of the auto-encoder training step (encoder convs, BN, the ConvTranspose2d backward with its
-    transposed-read bf16 MFMA weight-gradient GEMM, gemm_tn_bf16.hip): every gradient stays within bf16-storage distance
-    of the reference's autograd result, at the golden size and on a batch large enough to split K over many workgroups
-    (there against the library's own fp32 mode)."""
+    transposed-read bf16 MFMA weight-gradient GEMM, gemm_tn_bf16.hip), held to the ROUNDING-FAITHFUL training oracle
+    (oracle/torch_ref.py cae_train_step_emulated: float64 autograd with bf16 rounding where the kernels store e, z, zd, d and
+    the gradients de, dz, dzd, dd, bf16 MFMA weights, BatchNorm statistics of the stored tensors; without the roundings it
+    reproduces the reference's autograd goldens, tests/test_oracle_golden.py).  Measured on MI355X
+    (tools/gpu_cae_train_emu_probe.py): decoder gradients 0.01 % .. 1.5 %, encoder gradients 1 % .. 8 % of their scale on batches of
+    24 x 96 and 8 x 321 frames -- about half the distance at which the fp32 reference sits (1 % .. 20 %): seven BatchNorm + ReLU
+    layers amplify every re-rounding, so the oracle cannot pin this network as tightly as the three-block CNN2D (0.9 %).  Bounds:
+    10 % encoder / 3 % decoder on those batches (round 1 compared them with the library's own fp32 mode at 25 % / 5 %), 20 % on the
+    2 x 32-frame golden batch (25 %, against the reference's goldens, before)."""
     from dfa_amd.model_cae import ConvAutoencoder
+    from oracle import torch_ref as R
     _, g = golden("cae_train")
-    init = {k[len("init.sd."):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("init.sd.")}
+    sd = {k[len("init.sd."):]: v for k, v in g.items() if k.startswith("init.sd.")}
+    init = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
     noise = {f"encoder.{i}.bias" for i in (0, 4, 8, 12)} | {f"decoder.{i}.bias" for i in (0, 3, 6)}
 
-    def grads(prec, x):
-        m = ConvAutoencoder(precision=prec)
+    def gpu_grads(x):
+        m = ConvAutoencoder(precision="bf16")
         m.load_state_dict(init)
         m = m.to("cuda").train()
-        recon, _ = m(x)
-        torch.nn.MSELoss()(recon.float(), x.float()).backward()
-        return {n: p.grad.float().cpu().numpy() for n, p in m.named_parameters()}
+        xb = x.to("cuda").to(torch.bfloat16)
+        recon, _ = m(xb)
+        torch.nn.MSELoss()(recon.float(), xb.float()).backward()
+        return {n: p.grad.float().cpu() for n, p in m.named_parameters()}
 
-    x_small = torch.from_numpy(g["ls0.x"]).to("cuda")
     gen = torch.Generator().manual_seed(4)
-    x_big = torch.randn(24, 96, 180, generator=gen).to("cuda")
-    for x, ref in ((x_small, {n[len("ls0.grad."):]: v for n, v in g.items() if n.startswith("ls0.grad.")}),
-                   (x_big, grads("fp32", x_big))):
-        got = grads("bf16", x.to(torch.bfloat16))
-        for n, want in ref.items():
+    cases = [(torch.from_numpy(g["ls0.x"]), 0.20, 0.20),
+             (torch.randn(24, 96, 180, generator=gen), 0.10, 0.03),
+             (torch.randn(8, 321, 180, generator=gen) * 2.0, 0.10, 0.03)]
+    for x, tol_enc, tol_dec in cases:
+        got = gpu_grads(x)
+        _, emu = R.cae_train_step_emulated(sd, x, "bf16")
+        _, ref = R.cae_train_step_emulated(sd, x, None)
+        for n in got:
             if n in noise:
                 continue
-            rel = np.abs(got[n] - want).max() / max(np.abs(want).max(), 1e-6)
-            # bf16 storage of z / dz: coarse on the 2 x 32-frame golden batch (as for the CNN2D), tighter once the sums
-            # run over a real batch; the ConvTranspose2d weights (decoder.*) come from the bf16 GEMM
-            tol = 0.05 if (x.shape[0] > 2 and n.startswith("decoder") and n.endswith("weight")) else 0.25
-            assert rel < tol, (n, tuple(x.shape), rel)
+            scale = max(float(ref[n].abs().max()), 1e-9)
+            rel = float((got[n] - emu[n]).abs().max()) / scale
+            assert rel < (tol_dec if n.startswith("decoder") else tol_enc), (n, tuple(x.shape), rel)
 
 
 def test_train_cae_cli_end_to_end(tmp_path):
