@@ -38,12 +38,6 @@ struct SplitCfg {
 };
 
 enum { SPLIT_EPI_POOL_H2 = 0, SPLIT_EPI_MEAN_T = 1, SPLIT_EPI_PLAIN_BF16 = 2 };
-// A workgroup OWNS kStripW = 30 output columns (180 = 6 x 30: no ragged last strip) and loads the 32 columns f0-1 .. f0+30 around
-// them; the two 16-pixel MFMA tiles still cover 32 columns, the last two belong to the next strip and are dropped (their
-// inputs, ring slots 32 / 33, are never loaded -- MFMA columns are independent).  Against 32 owned columns + 34 loaded this
-// reads 6 % fewer bytes and, measured with the arithmetic-free walker tools/microbench/stream_pattern.hip, the access pattern
-// itself runs 8-20 % faster (4.7-5.2 vs 4.4 TB/s at the 32<->64-channel shapes).
-constexpr int kStripW = 30;
 
 static __device__ __forceinline__ f32x4_t mma16s(const uint4& w, const uint4& x, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
@@ -67,7 +61,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, xi = bid >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int b = logical / a.nstrips, strip = logical - b * a.nstrips;
-  const int f0 = strip * kStripW;
+  const int f0 = strip * 32;
   const int H = a.H, W = a.W;
   const char* in_b = (const char*)a.in + (size_t)b * H * W * PB;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -105,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     const int slot = rem / CPP, cph = rem % CPP;
     const int c = cph ^ C::swz(slot);
     const int f = f0 - 1 + slot;
-    const bool ok = (g < NCH) && (slot < kStripW + 2) && (f >= 0) && (f < W);
+    const bool ok = (g < NCH) && (slot < 34) && (f >= 0) && (f < W);
     s_off[k] = ok ? (rowi * W + f) * PB + c * 16 : -1;
   }
   auto stage_dma = [&](int j, int ringblk) {
@@ -218,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][2], acc[1][3]), false, false);
         const size_t oi = (((size_t)b * H + t0 + r) * W + col) * COUT + cb;
         uint4 o = make_uint4(d0[0], d1[0], d0[1], d1[1]);
-        pend_ok[r] = t0 + r < H && col < W && 16 * tile + p < kStripW;
+        pend_ok[r] = t0 + r < H && col < W;
         if (a.drop.thresh != 0 && pend_ok[r]) {       // one Philox call per 16-byte store
           unsigned km[4];
           drop_keep8(a.drop, oi, km);
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
       // after the swap: element [0] = channels 4*(q&~1).. of this lane's tile, element [1] = the next 4 channels
       const int tile = q & 1, cb = 16 * wave + 8 * (q >> 1);
       const int col = f0 + 16 * tile + p;
-      if (to < Ho && col < W && 16 * tile + p < kStripW) {
+      if (to < Ho && col < W) {
         bf16_t* o = (bf16_t*)a.out + (((size_t)b * Ho + to) * W + col) * (2 * COUT) + cb;
         *(uint4*)o = make_uint4(h0[0], h1[0], h0[1], h1[1]);
         *(uint4*)(o + COUT) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
@@ -284,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
           const int col = f0 + 16 * pb + p;
-          if (col < W && 16 * pb + p < kStripW) {
+          if (col < W) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) e0[((size_t)b * COUT + 16 * wave + 4 * q + e) * W + col] = cs[pb][e];
           }
@@ -305,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
       const f32x4_t tv = tot[pb];
-      if (col < W && 16 * pb + p < kStripW) {
+      if (col < W) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = 16 * wave + 4 * q + e;
@@ -378,14 +372,14 @@ static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
 // block 2: a.in = a1 split [B][H][W][2*32], a.out = a2 split [B][H/2][W][2*64]
 hipError_t launch_cnn2d_block2_split(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + kStripW - 1) / kStripW;
+  a.nstrips = (a.W + 31) / 32;
   return pipe ? launch_split_t<32, 4, SPLIT_EPI_POOL_H2, true>(a, stream) : launch_split_t<32, 4, SPLIT_EPI_POOL_H2, false>(a, stream);
 }
 
 // block 3: a.in = a2 split [B][H][W][2*64], a.emb = [B][128][W] fp32 (mean over H)
 hipError_t launch_cnn2d_block3_split(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + kStripW - 1) / kStripW;
+  a.nstrips = (a.W + 31) / 32;
   return pipe ? launch_split_t<64, 8, SPLIT_EPI_MEAN_T, true>(a, stream) : launch_split_t<64, 8, SPLIT_EPI_MEAN_T, false>(a, stream);
 }
 
@@ -421,7 +415,7 @@ hipError_t launch_pack_conv3x3_dgrad_m16(const float* w, int cin, int cout, uint
 // block 3 data gradient: a.in = dz3 [B][H][W][128] bf16, a.out = da2 [B][H][W][64] bf16 (one launch: no fp32 partial sums)
 hipError_t launch_train_dgrad3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + kStripW - 1) / kStripW;
+  a.nstrips = (a.W + 31) / 32;
   return pipe ? launch_split_t<128, 4, SPLIT_EPI_PLAIN_BF16, true, false>(a, stream)
               : launch_split_t<128, 4, SPLIT_EPI_PLAIN_BF16, false, false>(a, stream);
 }
@@ -429,7 +423,7 @@ hipError_t launch_train_dgrad3_m16(const ConvArgs& a0, hipStream_t stream, int p
 // block 2 data gradient: a.in = dz2 [B][H][W][64] bf16, a.out = da1 [B][H][W][32] bf16
 hipError_t launch_train_dgrad2_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + kStripW - 1) / kStripW;
+  a.nstrips = (a.W + 31) / 32;
   return pipe ? launch_split_t<64, 2, SPLIT_EPI_PLAIN_BF16, true, false>(a, stream)
               : launch_split_t<64, 2, SPLIT_EPI_PLAIN_BF16, false, false>(a, stream);
 }
