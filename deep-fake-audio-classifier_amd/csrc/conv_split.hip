@@ -43,6 +43,10 @@ static __device__ __forceinline__ f32x4_t mma16s(const uint4& w, const uint4& x,
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), c, 0, 0, 0);
 }
 
+#ifdef DFA_STAMPS   // diagnostic build (make stamps): per-wave cycle split of an iteration, printed by the launcher
+static __device__ long long g_diag_split[4096 * 8];
+#endif
+
 // NW waves = NW*16 output channels = COUT.  PIPE = false: the compiler-scheduled twin (bit-identical output).
 template <int CIN, int NW, int EPI, bool PIPE, bool SPLIT = true>
 __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
@@ -253,13 +257,29 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     }
   };
 
+#ifdef DFA_STAMPS
+  long long seg[4] = {0, 0, 0, 0};
+  long long t_prev = __builtin_amdgcn_s_memtime();
+  const long long t_begin = t_prev, r_begin = __builtin_amdgcn_s_memrealtime();
+  auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg[k] += t - t_prev; t_prev = t; };
+#else
+  auto stamp = [&](int) {};
+#endif
+  // (Stamped build: the five LDS-DMA pieces + two stores in front of the stream cost 1150-1220 cycles per wave-iteration of the
+  //  data-gradient kernels.  Issued from inside the MFMA stream instead, one every few consume steps, they cost the stream the
+  //  same cycles -- 5518 vs 5525 and 5000 vs 5092 per iteration: the wave is held by the memory pipeline, not by its place in
+  //  the program -- so they stay here.)
   auto iteration = [&](auto ph_c, int it) {
     constexpr int PH = decltype(ph_c)::value;
     flush_pending();
     if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
+    stamp(0);
     unit(ph_c, it);
+    stamp(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(2);
     __syncthreads();
+    stamp(3);
   };
   // MEAN_T: running total over the canonical chunks of the time mean (ConvArgs::chunk_iters), 8 floats per lane in LDS
   f32x4_t* const tot = (f32x4_t*)(smem + C::RING_BYTES + COUT * 4) + tid * 2;
@@ -292,6 +312,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   }
 
   flush_pending();               // the last iteration's rows
+#ifdef DFA_STAMPS
+  if (lane == 0 && blockIdx.x < 1024 && blockIdx.z == 0 && wave < 2) {
+    long long* dd = g_diag_split + ((size_t)blockIdx.x * 2 + wave) * 8;
+    for (int k = 0; k < 4; ++k) dd[k] = seg[k];
+    dd[4] = __builtin_amdgcn_s_memtime() - t_begin;
+    dd[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    dd[6] = niter - it0;
+  }
+#endif
   if constexpr (EPI == SPLIT_EPI_MEAN_T) {
     if (a.seg_iters) return;     // split: the classifier kernel adds and scales the chunk sums
     // embedding rows [b][channel][col]: 16 consecutive columns per (channel, quarter-wave)
@@ -366,6 +395,22 @@ static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
   }
   const int nseg = a.seg_iters ? ((a.H + 1) / 2 + a.seg_iters - 1) / a.seg_iters : 1;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nstrips, 1, nseg), dim3(64 * NW), LDS, stream, a);
+#ifdef DFA_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 30 && PIPE) {
+      static long long hbuf[4096 * 8];
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag_split), sizeof(hbuf));
+      const int nw = (a.B * a.nstrips < 1024 ? a.B * a.nstrips : 1024) * 2;
+      double m[6] = {0, 0, 0, 0, 0, 0}, iters = 0;
+      for (int i = 0; i < nw; ++i) { for (int k = 0; k < 6; ++k) m[k] += hbuf[i * 8 + k]; iters += hbuf[i * 8 + 6]; }
+      fprintf(stderr, "[stamps conv_split<%d,%d,epi %d,split %d>] cycles per wave-iteration: dma issue + stores %.0f  mfma stream + epilogue %.0f  "
+                      "dma wait %.0f  barrier %.0f  | lifetime/iteration %.0f  clock %.3f GHz\n", CIN, NW, EPI, (int)SPLIT,
+              m[0] / iters, m[1] / iters, m[2] / iters, m[3] / iters, m[4] / iters, m[4] / (m[5] * 10.0));
+    }
+  }
+#endif
   return hipGetLastError();
 }
 
