@@ -277,9 +277,16 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     const int t0 = BR * it + 2 * RPI;
     constexpr int NR = 12 * NKG;
     constexpr int S_RELU0 = 9 * NKG + 2;
-    // consume steps carrying block-1 pieces: the window reads are issued behind fragment read 1; by the wait of consume
-    // step 1 (all but the 3 youngest reads landed, those being fragment reads 2..4) they are in registers
-    constexpr int C_MFMA = 2, C_XLOAD = 4, C_PSTORE = 6, C_RELU = 8, C_STORE = 12, C_XSTORE = 16;
+    // The workgroup barrier of an iteration stands INSIDE the unit, behind fragment read S_BAR: what the unit reads before it
+    // (ring rows written two iterations ago) was published by the previous barrier, and what must not start before it -- the
+    // window reads of block it+2 (stored by the previous unit), the ring store at C_STORE (overwrites the block the previous
+    // unit read) and the reads of the rows the previous unit stored (second half of the stream) -- comes after it.  The
+    // unit's pipeline fill (the latency of its first fragment reads, ~400 cycles per iteration in the stamped build) thus
+    // overlaps the wait for the slower waves instead of following it.
+    // consume steps carrying block-1 pieces: the window reads are issued behind fragment read S_BAR; by the wait of consume
+    // step S_BAR + 1 (all but the 3 youngest reads landed, all of them younger than the window reads) they are in registers
+    constexpr int S_BAR = 4;
+    constexpr int C_MFMA = 5, C_XLOAD = 7, C_PSTORE = 9, C_RELU = 11, C_STORE = 15, C_XSTORE = 19;
     u32x4_t xbuf[PF];
     C1State c1;
     auto step = [&](auto s_c) {
@@ -288,7 +295,12 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
         constexpr int i = s / (3 * NKG), dx = (s / NKG) % 3, kg = s % NKG;
         constexpr int ringrow = (BR * PH + 2 * RPI + i) % (3 * BR);
         xbuf[s % PF] = lds_frag<ringrow * ROWB, PIPE>(lds0 + (xa[dx] ^ (kg << 5)));
-        if constexpr (s == 1) c1_issue(c1, it + 2);
+        if constexpr (s == S_BAR) {
+          // (this wave's own ring / window stores of the previous unit are complete: that unit's last counted wait is lgkmcnt(0))
+          if constexpr (PIPE) asm volatile("s_barrier" ::: "memory");
+          else __syncthreads();
+          c1_issue(c1, it + 2);
+        }
       }
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
@@ -298,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
         // the 2 ring stores issued behind consume step C_STORE and the 3 * NXLD window stores behind C_XSTORE.
         constexpr int young_r = (NR - 1 - c) < (PF - 1) ? (NR - 1 - c) : (PF - 1);
         constexpr int young = young_r + ((c > C_STORE && c <= C_STORE + PF - 1 && c < NR) ? 2 : 0) +
-                              ((c > C_XSTORE && c <= C_XSTORE + PF - 1 && c < NR) ? 3 * NXLD : 0);
+                              ((c > C_XSTORE && c <= C_XSTORE + PF - 1 && c < NR) ? 3 * NXLD : 0) +
+                              ((c > S_BAR - PF && c <= S_BAR) ? 2 : 0);      // the two window reads issued behind read S_BAR
         if constexpr (PIPE) lds_wait<young>(xbuf[c % PF]);
         const uint4 xv = __builtin_bit_cast(uint4, xbuf[c % PF]);
         if constexpr (i <= 2) acc0 = Mma<bf16_t>::run(w[i * 3 + dx][kg], xv, acc0);
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
       const unsigned ba = lds0 + BIAS2_OFF + (nsl * 32 + 4 * h) * 4;
       u32x4_t b0 = lds_frag<0, PIPE>(ba), b1 = lds_frag<32, PIPE>(ba), b2 = lds_frag<64, PIPE>(ba), b3 = lds_frag<96, PIPE>(ba);
       static_for(std::make_integer_sequence<int, PF - 1>{}, step);
-      if constexpr (PIPE) lds_wait4<PF - 1 + 2>(b0, b1, b2, b3);     // + the two window reads issued behind fragment read 1
+      if constexpr (PIPE) lds_wait4<PF - 1>(b0, b1, b2, b3);
       const u32x4_t bq[4] = {b0, b1, b2, b3};
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -353,8 +366,6 @@ __global__ __launch_bounds__(256, 2) void conv12_fused_kernel(Conv12Args a) {
     if (mg == 0) unit(ph_c, std::integral_constant<int, 0>{}, it);
     else unit(ph_c, std::integral_constant<int, 1>{}, it);
     stamp(2);
-    __syncthreads();
-    stamp(3);
   };
   stamp(5);
   for (int it = it0; it < niter_seg; it += 3) {
