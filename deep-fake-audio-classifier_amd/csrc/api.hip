@@ -316,10 +316,9 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   // Small batches (B * strips below the chip's resident-workgroup count; the reference's predict.py default is batch 32):
   // every workgroup would walk the whole time axis alone, so the axis is split into segments that separate workgroups walk
   // (blocks 1+2: disjoint output rows; block 3: partial means per segment, added up by the classifier kernel).
-  const int nstrips32 = (F + 31) / 32;
+  const int nstrips32 = (F + 31) / 32, nstrips30 = (F + 29) / 30;     // conv_split / conv3x3_mfma own 32 columns per strip, conv12_fused and conv3_m16 30
   if (fused12) {
     ScopedSlot ts(ctx, 1);
-    const int nstrips30 = (F + 29) / 30;
     const int seg12 = seg_iters_for((pl.H1 + 3) / 4, B * nstrips30, 512, 6, ctx->time_split);
     DFA_HIP_CHECK(ctx, launch_conv12_fused(x, x_dtype, stride_b, stride_t, stride_f, m.c1pack, m.c1bias, m.c2.wpack, m.c2.bias, a2,
                                            B, T, F, s, ctx->lds_pipe, seg12));
@@ -348,7 +347,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
       a.seg_iters = seg_iters_for(niter3, B * nstrips32, 256, chunk3, ctx->time_split);
     } else if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
       a.chunk_iters = chunk3;
-      a.seg_iters = seg_iters_for(niter3, B * nstrips32, 512, chunk3, ctx->time_split);
+      a.seg_iters = seg_iters_for(niter3, B * nstrips30, 512, chunk3, ctx->time_split);
     }
     if (a.seg_iters) {           // one slab of (unscaled) sums per canonical chunk in the workspace; the classifier kernel adds them
       nseg3 = (niter3 + chunk3 - 1) / chunk3;

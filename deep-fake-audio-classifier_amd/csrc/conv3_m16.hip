@@ -24,7 +24,11 @@ namespace dfa {
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 namespace m16 {
-constexpr int PB = 128, CPP = 8, SP = 36, ROWB = SP * PB, BR = 2, NSL = 4, NT = 256;
+// A workgroup OWNS SW = 30 output columns (180 = 6 x 30) and loads the SP = 32 columns f0-1 .. f0+30 around them: a ring block is
+// then exactly two 1-KiB LDS-DMA pieces per wave (no partial piece, no branch in the staging code, which runs inside the unit's
+// asm-read window).  The two 16-pixel MFMA tiles still cover 32 columns; the last two belong to the next strip and are
+// dropped (their inputs, slots 32 / 33, are whatever follows in LDS -- MFMA columns are independent).
+constexpr int PB = 128, CPP = 8, SP = 32, SW = 30, ROWB = SP * PB, BR = 2, NSL = 4, NT = 256;
 constexpr int NCH = BR * SP * CPP, NLD = (NCH + NT - 1) / NT;
 constexpr int RING_BYTES = 3 * BR * ROWB, BIAS_BYTES = NSL * 32 * 4, TOT_BYTES = NT * 64;   // running time-mean total: 16 floats per lane
 constexpr int LDS_BYTES = RING_BYTES + BIAS_BYTES + TOT_BYTES;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, xi = bid >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int b = logical / a.nstrips, strip = logical - b * a.nstrips;
-  const int f0 = strip * 32;
+  const int f0 = strip * SW;
   const int H = a.H, W = a.W, COUT = a.COUT;
   const int cout_base = blockIdx.y * (NSL * 32);
   const char* in_b = (const char*)a.in + (size_t)b * H * W * PB;
@@ -96,14 +100,15 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     const int slot = rem / CPP, cph = rem % CPP;
     const int c = cph ^ swz(slot);
     const int f = f0 - 1 + slot;
-    const bool ok = (g < NCH) && (slot < 34) && (f >= 0) && (f < W);
+    const bool ok = (f >= 0) && (f < W);
     s_off[k] = ok ? (rowi * W + f) * PB + c * 16 : -1;
   }
   auto stage_dma = [&](int j, int ringblk) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int g = k * NT + tid;
-      if (g < NCH) {
+      static_assert(NCH == NLD * NT, "a ring block is exactly NLD 1-KiB pieces per wave: no conditional piece");
+      {
         const int t = BR * j - 1 + g / (SP * CPP);
         const char* src = (s_off[k] >= 0 && t >= 0 && t < H) ? in_b + (ptrdiff_t)(BR * j - 1) * W * PB + s_off[k]
                                                              : (const char*)a.zero_page;
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     f32x4_t acc0[2][2], acc1[2][2];
     constexpr int NR = 4 * 3 * 2 * 2;   // fragment reads in (row i, dx, kk, pb) order
     constexpr int C_RELU0 = 36 + 3;     // acc0's last MFMAs belong to read 35
+    constexpr int S_BAR = 4;
     u32x4_t xbuf[PF];
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
@@ -142,6 +148,16 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
         constexpr int i = s / 12, dx = (s / 4) % 3, kk = (s / 2) % 2, pb = s % 2;
         constexpr int ringrow = (BR * PH + i) % (3 * BR);
         xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, PIPE>(lds0 + (xa[dx] ^ (kk << 6)));
+        if constexpr (s == S_BAR) {
+          // The iteration's barrier stands here, behind the unit's first fragment reads (rows of ring block `it`, published
+          // two barriers ago), so the pipeline fill overlaps the wait for the slower waves.  Behind it: the LDS-DMA of block
+          // it+2 (overwrites the block the previous unit read) and, from read 24 on, the rows of block it+1 (DMA'd during the
+          // previous unit: every wave waits for its own pieces, vmcnt(0), before the barrier).
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (PIPE) asm volatile("s_barrier" ::: "memory");
+          else __syncthreads();
+          if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
+        }
       }
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
       // statistics of the fp32 accumulators (as the 32x32x16 kernel); rows / columns outside the image do not count
 #pragma unroll
       for (int pb = 0; pb < 2; ++pb) {
-        const bool cok = f0 + 16 * pb + p < W;
+        const bool cok = 16 * pb + p < SW && f0 + 16 * pb + p < W;
 #pragma unroll
         for (int ca = 0; ca < 2; ++ca) {
           if (cok && r0) {
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
           const f32x4_t v0 = r ? acc1[ca][0] : acc0[ca][0], v1 = r ? acc1[ca][1] : acc0[ca][1];
           const auto d0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
           const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
-          if (col < W && (r ? r1 : r0)) *(uint4*)(zb + (size_t)r * W * COUT + 16 * ca) = make_uint4(d0[0], d1[0], d0[1], d1[1]);
+          if (16 * tile + p < SW && col < W && (r ? r1 : r0)) *(uint4*)(zb + (size_t)r * W * COUT + 16 * ca) = make_uint4(d0[0], d1[0], d0[1], d1[1]);
         }
       }
     } else
@@ -230,13 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     }
   };
 
-  auto iteration = [&](auto ph_c, int it) {
-    constexpr int PH = decltype(ph_c)::value;
-    if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
-    unit(ph_c, it);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
+  auto iteration = [&](auto ph_c, int it) { unit(ph_c, it); };      // (DMA issue, DMA wait and the barrier are inside the unit)
   f32x4_t* const tot = (f32x4_t*)(smem + RING_BYTES + BIAS_BYTES) + tid * 4;   // eval: total over the canonical chunks
   if constexpr (!TRAIN) {
 #pragma unroll
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
           for (int pb = 0; pb < 2; ++pb) {
             const int col = f0 + 16 * pb + p;
-            if (col < W) {
+            if (16 * pb + p < SW && col < W) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 e0[((size_t)b * COUT + cout_base + nsl * 32 + 16 * ca + 4 * q + e) * W + col] = cs[ca][pb][e];
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
       const f32x4_t tv = tot[ca * 2 + pb];
-      if (col < W) {
+      if (16 * pb + p < SW && col < W) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = cout_base + nsl * 32 + 16 * ca + 4 * q + e;
@@ -399,14 +409,14 @@ static hipError_t launch_m16_t(const ConvArgs& a, hipStream_t stream) {
 
 hipError_t launch_cnn2d_block3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+  a.nstrips = (a.W + m16::SW - 1) / m16::SW;
   return pipe ? launch_m16_t<true, false>(a, stream) : launch_m16_t<false, false>(a, stream);
 }
 
 // train-mode forward of block 3: a.out = z [B][H][W][128] bf16, a.stats_partial = [B*nstrips][128][2]
 hipError_t launch_train_fwd3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+  a.nstrips = (a.W + m16::SW - 1) / m16::SW;
   return pipe ? launch_m16_t<true, true>(a, stream) : launch_m16_t<false, true>(a, stream);
 }
 

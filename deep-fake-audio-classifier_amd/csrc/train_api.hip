@@ -63,7 +63,7 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
   p.raw = take((size_t)B * p.H2 * F * 64 * 4);
   p.stats = take((32 + 64 + 128) * 3 * 4);          // mean | var | invstd per layer
   p.sums = take((32 + 64 + 128) * 2 * 4 + 352 * 4 + 96 * 4);  // (S1,S2) per layer + conv1 backward record [32][11] + XX[9][9] | Xs[9]
-  const int nstrips = (F + 31) / 32;
+  const int nstrips = (F + 29) / 30;                                         // (the 30-column strips of conv3_m16: >= the 32-column count)
   size_t pb = (size_t)B * nstrips * 128 * 2 * 4;                              // conv stats partials
   pb = std::max(pb, ((size_t)conv1_train_blocks(B, T, F) + 64) * 352 * 4);   // conv1 passes + 2nd-level scratch
   int ppb;
@@ -222,7 +222,7 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     }
   }
   StatPtrs s3 = stat_ptrs(ws, pl, 2);
-  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * nstrips, 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, s));
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * (fwd3_m16 ? (F + 29) / 30 : nstrips), 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, s));   // conv3_m16 owns 30 columns per strip
   float* emb = (float*)(ws + pl.emb);
   DFA_HIP_CHECK(ctx, launch_bn_relu_meant(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], emb, B, pl.H2, F, 128, s, (float*)(ws + pl.msum)));
   if (embedding) DFA_HIP_CHECK(ctx, hipMemcpyAsync(embedding, emb, (size_t)B * 128 * F * 4, hipMemcpyDeviceToDevice, s));
