@@ -316,7 +316,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   // Small batches (B * strips below the chip's resident-workgroup count; the reference's predict.py default is batch 32):
   // every workgroup would walk the whole time axis alone, so the axis is split into segments that separate workgroups walk
   // (blocks 1+2: disjoint output rows; block 3: partial means per segment, added up by the classifier kernel).
-  const int nstrips32 = (F + 31) / 32, nstrips30 = (F + 29) / 30;     // conv_split / conv3x3_mfma own 32 columns per strip, conv12_fused and conv3_m16 30
+  const int nstrips30 = (F + 29) / 30;     // conv12_fused, conv3_m16 and conv_split own 30 columns per strip (conv3x3_mfma 32)
   if (fused12) {
     ScopedSlot ts(ctx, 1);
     const int seg12 = seg_iters_for((pl.H1 + 3) / 4, B * nstrips30, 512, 6, ctx->time_split);
@@ -331,7 +331,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     ConvArgs a{};
     a.in = a1; a.wpack = m.c2.wpack; a.bias = m.c2.bias; a.out = a2; a.emb = nullptr;
     a.B = B; a.H = pl.H1; a.W = F; a.COUT = 64; a.inv_h = 0.f; a.relu = 1; a.zero_page = ctx->zero_page;
-    if (prec == DFA_PREC_BF16X3) a.seg_iters = seg_iters_for((pl.H1 + 1) / 2, B * nstrips32, 768, 3, ctx->time_split);
+    if (prec == DFA_PREC_BF16X3) a.seg_iters = seg_iters_for((pl.H1 + 1) / 2, B * nstrips30, 768, 3, ctx->time_split);
     if (prec == DFA_PREC_BF16X3) DFA_HIP_CHECK(ctx, launch_cnn2d_block2_split(a, s, ctx->lds_pipe));
     else DFA_HIP_CHECK(ctx, launch_cnn2d_block2(prec, a, s, ctx->conv_dma, ctx->lds_pipe));
   }
@@ -344,7 +344,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     const int chunk3 = 6 * std::max(2, (niter3 + 6 * kMaxSeg - 1) / (6 * kMaxSeg));   // canonical chunks: depend on T only (12 iterations = 24 rows for T = 321), <= kMaxSeg of them
     if (prec == DFA_PREC_BF16X3) {
       a.chunk_iters = chunk3;
-      a.seg_iters = seg_iters_for(niter3, B * nstrips32, 256, chunk3, ctx->time_split);
+      a.seg_iters = seg_iters_for(niter3, B * nstrips30, 256, chunk3, ctx->time_split);
     } else if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
       a.chunk_iters = chunk3;
       a.seg_iters = seg_iters_for(niter3, B * nstrips30, 512, chunk3, ctx->time_split);

@@ -32,7 +32,10 @@ struct SplitCfg {
   static constexpr int KK = CIN / 32;            // k-steps of 32 input channels
   static constexpr int HL = SPLIT ? 2 : 1;
   static_assert(PB == 128 || PB == 256, "swizzles exist for 128- and 256-byte pixels");
-  static constexpr int SP = 36, ROWB = SP * PB, BR = 2;
+  // A workgroup OWNS SW = 30 output columns (180 = 6 x 30) and loads the SP = 32 columns f0-1 .. f0+30 around them (as
+  // conv3_m16.hip: a ring block is a whole number of 1-KiB LDS-DMA pieces per wave, the staging code has no branch and can run
+  // inside the unit's asm-read window; the two MFMA tiles' last two columns belong to the next strip and are dropped)
+  static constexpr int SP = 32, SW = 30, ROWB = SP * PB, BR = 2;
   static constexpr int RING_BYTES = 3 * BR * ROWB;
   static __device__ __forceinline__ int swz(int slot) { return CPP == 8 ? (slot & 6) : ((slot & 7) << 1); }
 };
@@ -51,10 +54,11 @@ static __device__ long long g_diag_split[4096 * 8];
 template <int CIN, int NW, int EPI, bool PIPE, bool SPLIT = true>
 __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   using C = SplitCfg<CIN, SPLIT>;
-  constexpr int PB = C::PB, CPP = C::CPP, KK = C::KK, HL = C::HL, SP = C::SP, ROWB = C::ROWB, BR = C::BR, NT = 64 * NW;
+  constexpr int PB = C::PB, CPP = C::CPP, KK = C::KK, HL = C::HL, SP = C::SP, SW = C::SW, ROWB = C::ROWB, BR = C::BR, NT = 64 * NW;
   static_assert(SPLIT || EPI == SPLIT_EPI_PLAIN_BF16, "the plain-bf16 form is the data-gradient convolution");
   constexpr int COUT = 16 * NW;
-  constexpr int NCH = BR * SP * CPP, NLD = (NCH + NT - 1) / NT;
+  constexpr int NCH = BR * SP * CPP, NLD = NCH / NT;
+  static_assert(NCH == NLD * NT, "a ring block is exactly NLD 1-KiB pieces per wave: no conditional piece");
   constexpr int PF = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, xi = bid >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
   const int b = logical / a.nstrips, strip = logical - b * a.nstrips;
-  const int f0 = strip * 32;
+  const int f0 = strip * SW;
   const int H = a.H, W = a.W;
   const char* in_b = (const char*)a.in + (size_t)b * H * W * PB;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -103,14 +107,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     const int slot = rem / CPP, cph = rem % CPP;
     const int c = cph ^ C::swz(slot);
     const int f = f0 - 1 + slot;
-    const bool ok = (g < NCH) && (slot < 34) && (f >= 0) && (f < W);
+    const bool ok = (f >= 0) && (f < W);
     s_off[k] = ok ? (rowi * W + f) * PB + c * 16 : -1;
   }
   auto stage_dma = [&](int j, int ringblk) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int g = k * NT + tid;
-      if (g < NCH) {
+      {
         const int t = BR * j - 1 + g / (SP * CPP);
         const char* src = (s_off[k] >= 0 && t >= 0 && t < H) ? in_b + (ptrdiff_t)(BR * j - 1) * W * PB + s_off[k]
                                                              : (const char*)a.zero_page;
@@ -132,6 +136,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+#ifdef DFA_STAMPS
+  long long seg[4] = {0, 0, 0, 0};
+  long long t_prev = __builtin_amdgcn_s_memtime();
+  const long long t_begin = t_prev, r_begin = __builtin_amdgcn_s_memrealtime();
+  auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg[k] += t - t_prev; t_prev = t; };
+#else
+  auto stamp = [&](int) {};
+#endif
   // PLAIN_BF16: the two output rows of an iteration wait in registers and are stored at the START of the next iteration, in
   // front of its LDS-DMA loads: the iteration's closing vmcnt(0) (needed for the DMA before the barrier) counts stores too, and
   // with the stores issued right before it every iteration paid a full write round trip
@@ -152,6 +164,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     constexpr int PER_ROW = 3 * KK * HL * 2;       // fragment reads per input row, in (dx, kk, hi|lo, pixel tile) order
     constexpr int NR = 4 * PER_ROW;
     constexpr int C_RELU0 = 3 * PER_ROW + 2;       // acc0's last MFMAs belong to consume step 3*PER_ROW - 1
+    // The data-gradient form keeps its barrier at the iteration boundary: its deferred output stores are lane-conditional, and
+    // exec branches are not allowed inside the asm-read window (tools/check_lds_pipeline.py).
+    constexpr int S_BAR = 4;
+    constexpr bool INBAR = EPI != SPLIT_EPI_PLAIN_BF16;
     u32x4_t xbuf[PF];
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
@@ -160,6 +176,20 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         constexpr int ringrow = (BR * PH + i) % (3 * BR);
         constexpr int c0 = hl * (CPP / 2) + 4 * kk;
         xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, PIPE>(lds0 + (xa[dx] ^ (c0 << 4)));
+        if constexpr (INBAR && s == S_BAR) {
+          // the iteration's barrier, behind the unit's first fragment reads (rows of ring block `it`, published two barriers ago:
+          // the pipeline fill overlaps the wait for the slower waves); behind it the previous unit's output stores, the LDS-DMA
+          // of block it+2 (overwrites the block the previous unit read) and, in the second half of the stream, the rows of block
+          // it+1 (every wave waited for its own pieces, vmcnt(0), before the barrier)
+          stamp(1);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp(2);
+          if constexpr (PIPE) asm volatile("s_barrier" ::: "memory");
+          else __syncthreads();
+          stamp(3);
+          if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
+          stamp(0);
+        }
       }
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
@@ -216,7 +246,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][2], acc[1][3]), false, false);
         const size_t oi = (((size_t)b * H + t0 + r) * W + col) * COUT + cb;
         uint4 o = make_uint4(d0[0], d1[0], d0[1], d1[1]);
-        pend_ok[r] = t0 + r < H && col < W;
+        pend_ok[r] = t0 + r < H && col < W && 16 * tile + p < SW;
         if (a.drop.thresh != 0 && pend_ok[r]) {       // one Philox call per 16-byte store
           unsigned km[4];
           drop_keep8(a.drop, oi, km);
@@ -249,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
       // after the swap: element [0] = channels 4*(q&~1).. of this lane's tile, element [1] = the next 4 channels
       const int tile = q & 1, cb = 16 * wave + 8 * (q >> 1);
       const int col = f0 + 16 * tile + p;
-      if (to < Ho && col < W) {
+      if (to < Ho && col < W && 16 * tile + p < SW) {
         bf16_t* o = (bf16_t*)a.out + (((size_t)b * Ho + to) * W + col) * (2 * COUT) + cb;
         *(uint4*)o = make_uint4(h0[0], h1[0], h0[1], h1[1]);
         *(uint4*)(o + COUT) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
@@ -257,29 +287,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     }
   };
 
-#ifdef DFA_STAMPS
-  long long seg[4] = {0, 0, 0, 0};
-  long long t_prev = __builtin_amdgcn_s_memtime();
-  const long long t_begin = t_prev, r_begin = __builtin_amdgcn_s_memrealtime();
-  auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg[k] += t - t_prev; t_prev = t; };
-#else
-  auto stamp = [&](int) {};
-#endif
-  // (Stamped build: the five LDS-DMA pieces + two stores in front of the stream cost 1150-1220 cycles per wave-iteration of the
-  //  data-gradient kernels.  Issued from inside the MFMA stream instead, one every few consume steps, they cost the stream the
-  //  same cycles -- 5518 vs 5525 and 5000 vs 5092 per iteration: the wave is held by the memory pipeline, not by its place in
-  //  the program -- so they stay here.)
   auto iteration = [&](auto ph_c, int it) {
-    constexpr int PH = decltype(ph_c)::value;
-    flush_pending();
-    if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
-    stamp(0);
-    unit(ph_c, it);
-    stamp(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp(2);
-    __syncthreads();
-    stamp(3);
+    if constexpr (EPI != SPLIT_EPI_PLAIN_BF16) {
+      unit(ph_c, it);              // DMA wait, barrier and DMA issue are inside the unit
+    } else {
+      constexpr int PH = decltype(ph_c)::value;
+      flush_pending();
+      if (it + 1 < niter) stage_dma(it + 2, (PH + 2) % 3);
+      stamp(0);
+      unit(ph_c, it);
+      stamp(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(2);
+      __syncthreads();
+      stamp(3);
+    }
   };
   // MEAN_T: running total over the canonical chunks of the time mean (ConvArgs::chunk_iters), 8 floats per lane in LDS
   f32x4_t* const tot = (f32x4_t*)(smem + C::RING_BYTES + COUT * 4) + tid * 2;
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
           const int col = f0 + 16 * pb + p;
-          if (col < W) {
+          if (col < W && 16 * pb + p < SW) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) e0[((size_t)b * COUT + 16 * wave + 4 * q + e) * W + col] = cs[pb][e];
           }
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
       const f32x4_t tv = tot[pb];
-      if (col < W) {
+      if (col < W && 16 * pb + p < SW) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int c = 16 * wave + 4 * q + e;
@@ -405,7 +427,7 @@ static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
       const int nw = (a.B * a.nstrips < 1024 ? a.B * a.nstrips : 1024) * 2;
       double m[6] = {0, 0, 0, 0, 0, 0}, iters = 0;
       for (int i = 0; i < nw; ++i) { for (int k = 0; k < 6; ++k) m[k] += hbuf[i * 8 + k]; iters += hbuf[i * 8 + 6]; }
-      fprintf(stderr, "[stamps conv_split<%d,%d,epi %d,split %d>] cycles per wave-iteration: dma issue + stores %.0f  mfma stream + epilogue %.0f  "
+      fprintf(stderr, "[stamps conv_split<%d,%d,epi %d,split %d>] cycles per wave-iteration: stores + dma issue %.0f  mfma stream + epilogue %.0f  "
                       "dma wait %.0f  barrier %.0f  | lifetime/iteration %.0f  clock %.3f GHz\n", CIN, NW, EPI, (int)SPLIT,
               m[0] / iters, m[1] / iters, m[2] / iters, m[3] / iters, m[4] / iters, m[4] / (m[5] * 10.0));
     }
@@ -417,14 +439,14 @@ static hipError_t launch_split_t(const ConvArgs& a, hipStream_t stream) {
 // block 2: a.in = a1 split [B][H][W][2*32], a.out = a2 split [B][H/2][W][2*64]
 hipError_t launch_cnn2d_block2_split(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+  a.nstrips = (a.W + 29) / 30;
   return pipe ? launch_split_t<32, 4, SPLIT_EPI_POOL_H2, true>(a, stream) : launch_split_t<32, 4, SPLIT_EPI_POOL_H2, false>(a, stream);
 }
 
 // block 3: a.in = a2 split [B][H][W][2*64], a.emb = [B][128][W] fp32 (mean over H)
 hipError_t launch_cnn2d_block3_split(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+  a.nstrips = (a.W + 29) / 30;
   return pipe ? launch_split_t<64, 8, SPLIT_EPI_MEAN_T, true>(a, stream) : launch_split_t<64, 8, SPLIT_EPI_MEAN_T, false>(a, stream);
 }
 
@@ -460,7 +482,7 @@ hipError_t launch_pack_conv3x3_dgrad_m16(const float* w, int cin, int cout, uint
 // block 3 data gradient: a.in = dz3 [B][H][W][128] bf16, a.out = da2 [B][H][W][64] bf16 (one launch: no fp32 partial sums)
 hipError_t launch_train_dgrad3_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+  a.nstrips = (a.W + 29) / 30;
   return pipe ? launch_split_t<128, 4, SPLIT_EPI_PLAIN_BF16, true, false>(a, stream)
               : launch_split_t<128, 4, SPLIT_EPI_PLAIN_BF16, false, false>(a, stream);
 }
@@ -468,7 +490,7 @@ hipError_t launch_train_dgrad3_m16(const ConvArgs& a0, hipStream_t stream, int p
 // block 2 data gradient: a.in = dz2 [B][H][W][64] bf16, a.out = da1 [B][H][W][32] bf16
 hipError_t launch_train_dgrad2_m16(const ConvArgs& a0, hipStream_t stream, int pipe) {
   ConvArgs a = a0;
-  a.nstrips = (a.W + 31) / 32;
+  a.nstrips = (a.W + 29) / 30;
   return pipe ? launch_split_t<64, 2, SPLIT_EPI_PLAIN_BF16, true, false>(a, stream)
               : launch_split_t<64, 2, SPLIT_EPI_PLAIN_BF16, false, false>(a, stream);
 }
