@@ -169,8 +169,37 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream) {
 
 const char* dfa_last_error(const dfa_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+namespace {
+// Test hook ("poison_lds"): fills the whole 160 KB of LDS of every CU with a 16-bit pattern (0x7fc0 = bf16 NaN, 0xffff = NaN in
+// either width).  LDS is not cleared between workgroups, so a kernel that lets bytes it never wrote reach a result shows up in the
+// parity tests that run after this instead of once in a few thousand launches.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  constexpr int N = 160 * 1024 / 4;
+  for (int i = threadIdx.x; i < N; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  __builtin_amdgcn_s_sleep(127);
+  if (lds_words[(threadIdx.x * 97 + blockIdx.x) % N] != pattern) sink[0] = 1;   // keeps the stores; never true
+}
+hipError_t launch_poison_lds(dfa_ctx* ctx, unsigned half) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  half &= 0xffffu;
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, ctx->stream, half | (half << 16), (unsigned*)ctx->zero_page);
+  return hipGetLastError();
+}
+}  // namespace
+
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return DFA_E_NULL_PTR;
+  if (strcmp(name, "poison_lds") == 0) {
+    hipError_t e = launch_poison_lds(ctx, (unsigned)value);
+    return e == hipSuccess ? DFA_OK : fail(ctx, DFA_E_HIP, "poison_lds: %s", hipGetErrorString(e));
+  }
   if (strcmp(name, "train_conv_variant") == 0) { set_train_conv_variant(value); return DFA_OK; }
   if (strcmp(name, "wgrad_variant") == 0) { set_wgrad_variant(value); return DFA_OK; }
   if (strcmp(name, "time_split") == 0) { ctx->time_split = value; return DFA_OK; }

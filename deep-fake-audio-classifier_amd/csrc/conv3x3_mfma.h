@@ -484,11 +484,13 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
         v1[i] = a.relu ? relu1(acc1[i], rlim) : acc1[i];
       }
       if (STATS) {
-        const float m0 = r0ok ? 1.f : 0.f, m1 = r1ok ? 1.f : 0.f;
+        // selects, not 0/1 multipliers: a masked lane's accumulators are products of whatever its LDS slots held; with operands
+        // that are not staged zeros (tried: 30-column strips, whose two spare lanes read past the ring) 0 * NaN poisons the sums
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          st1[i] += m0 * v0[i] + m1 * v1[i];
-          st2[i] += m0 * v0[i] * v0[i] + m1 * v1[i] * v1[i];
+          const float u0 = r0ok ? v0[i] : 0.f, u1 = r1ok ? v1[i] : 0.f;
+          st1[i] += u0 + u1;
+          st2[i] += u0 * u0 + u1 * u1;
         }
       }
       T* o0 = (T*)a.out + (((size_t)b * H + t0) * W + col) * COUT + nb;

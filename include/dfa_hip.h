@@ -88,6 +88,9 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   earlier 4-wave kernel (process-wide)
  *   "train_conv_variant" 2 (default) = pipelined two-wave bf16 training convolutions where they fit, 0 = their
  *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
+ *   "poison_lds"    (action, test hook) fills all 160 KB of LDS of every CU with the 16-bit pattern `value` (0xffff / 0x7fc0 =
+ *                   NaN, 0x7f80 = +Inf) on the context's stream.  LDS is not cleared between workgroups; the stale-LDS tests
+ *                   (tests/test_lds_poison_gpu.py) run every path after this and require bit-identical results
  * unknown names return DFA_E_UNSUPPORTED */
 int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value);
 const char* dfa_last_error(const dfa_ctx* ctx);

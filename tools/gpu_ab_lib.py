@@ -15,14 +15,16 @@ if os.environ.get("DFA_AB_MODE") == "train":
     x = (torch.randn(256, 180, 321, generator=g) * 3.2 - 0.07).to(dev, dtype=torch.bfloat16).transpose(1, 2)
     y = (torch.rand(256, generator=g) > 0.5).float().to(dev)
     torch.manual_seed(0)
-    tr = NativeTrainer(CNN2D(dropout=0.2, precision="bf16").to(dev), label_smoothing=0.05)
-    for _ in range(5): tr.step(x, y)
+    tr = NativeTrainer(CNN2D(dropout=0.2, precision="bf16").to(dev), label_smoothing=0.05,
+                       lr=float(os.environ.get("DFA_AB_LR", "1e-6")))   # tiny lr: both builds time the same activation regime
+    losses = [float(tr.step(x, y)) for _ in range(5)]
     res = []
     for rnd in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): tr.step(x, y)
+        for _ in range(10): last = tr.step(x, y)
         torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 10 * 1e3)
-    print(name, "train step ms median %.3f min %.3f" % (sorted(res)[2], min(res)), flush=True)
+    print(name, "train step ms median %.3f min %.3f" % (sorted(res)[2], min(res)),
+          "losses", ["%.4f" % v for v in losses], "last %.4f" % float(last), flush=True)
     sys.exit(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(1234)
