@@ -59,10 +59,13 @@ def test_cnn2d_training_steps_ignore_stale_lds(prec, B):
     x = _stored(B, 31, dtype=torch.bfloat16 if prec == "bf16" else torch.float32)
     y = (torch.rand(B, generator=torch.Generator().manual_seed(2)) > 0.5).float().to("cuda")
 
-    def run(pattern):
+    def run(pattern, ws_byte=None):
         torch.manual_seed(5)
         model = CNN2D(in_features=180, dropout=0.2, precision=prec).to("cuda")
         model._drop_seed = 99
+        if ws_byte is not None:       # the workspace the C ABI is handed is uninitialised memory: make it hostile
+            n = _ctx().lib.dfa_cnn2d_train_workspace_bytes(_ctx().handle, B, 321, 180, _lib.PRECISIONS[prec])
+            model._train_ws = torch.full((int(n),), ws_byte, dtype=torch.uint8, device="cuda")
         tr = NativeTrainer(model, lr=1e-3, label_smoothing=0.05)
         losses = []
         for _ in range(3):
@@ -71,12 +74,17 @@ def test_cnn2d_training_steps_ignore_stale_lds(prec, B):
             losses.append(tr.step(x, y).clone())
         return torch.cat(losses), tr.flat_g.clone(), tr.flat_p.clone(), model.conv[6].running_var.clone()
 
+    from dfa_amd import _lib
     want = run(None)
     assert all(torch.isfinite(t).all() for t in want)
     for pat in PATTERNS:
         got = run(pat)
         for u, v in zip(got, want):
             assert torch.equal(u, v), hex(pat)
+    for ws_byte in (0xFF, 0x7F):      # workspace pre-filled with NaN patterns (bf16 0xffff / 0x7f7f = 3.4e38, fp32 NaN / 3.4e38)
+        got = run(None, ws_byte)
+        for u, v in zip(got, want):
+            assert torch.equal(u, v), hex(ws_byte)
 
 
 def test_cnn2d_long_training_run_stays_finite():
