@@ -311,6 +311,9 @@ __device__ __forceinline__ u32x2_t lds_tr(unsigned addr) {
 // return zeros without memory traffic and without a branch, so the loads of an item issue back to back with counted waits
 // (under exec branches every wait was vmcnt(0)).  Two items in flight (a second register set) were measured with this form:
 // 0.684 vs 0.681 ms for the 64 -> 128 layer -- the kernel is not waiting for its prefetch -- and dropped.
+#ifdef DFA_STAMPS   // diagnostic build (make stamps): per-wave cycle split of an item, printed by the launcher
+static __device__ long long g_diag_wgrad[256 * 8 * 8];
+#endif
 template <int CIN, int COUT, int SEG, int ROWS, int KS, bool PIPE>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ a,
                                                                   float* __restrict__ partial, int B, int H, int W,
@@ -342,34 +345,88 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
 
   const int nseg = (W + SEG - 1) / SEG, nrp = (H + ROWS - 1) / ROWS;
   const long nitems = (long)B * nrp * nseg;
-  uint4 sdz[NDZ], sa[NA];
+  // The next item's tiles come through bounds-checked buffer loads (out-of-image / out-of-tile lanes get an out-of-range
+  // offset: zeros without traffic or branches).  PIPE: the NP = NDZ + NA loads of a thread are asm statements spread evenly
+  // through the MFMA stream of the current item -- issued together in front of it they sat in the CU's memory pipeline's
+  // queue and BLOCKED their waves for 1556 of an item's 4861 cycles (stamps build), with the memory system then idle
+  // through compute, LDS store and barrier.  The compiler sees the asm outputs as ready at once; the s_waitcnt vmcnt(0)
+  // in front of store_item carries them as "+v" operands (same contract as the LDS fragment reads).
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int NP = NDZ + NA;
+  u32x4_t sdz[NDZ], sa[NA];
   constexpr unsigned OOR = 0xfffffff0u;              // beyond every buffer: the load returns zeros
   const unsigned dz_bytes = (unsigned)((size_t)H * W * dzs_c * 2), a_bytes = (unsigned)((size_t)H * W * as_c * 2);
-  auto load_item = [&](long item_) {                 // global -> registers (zeros outside the image and the tile)
+  // buffer descriptors of the item being fetched (wave-uniform): {base lo, base hi, bytes, raw-buffer flags}; the asm form
+  // takes them as SGPR quads, the compiler-scheduled twin as the builtin's resource type
+  i32x4_t rdz = {0, 0, 0, 0}, ra = {0, 0, 0, 0};
+  const bf16_t *pdz = dz, *pa = a;
+  unsigned live_dz = 0, live_a = 0;
+  int ld_t0 = 0, ld_f0 = 0;
+  // (item -> (image, row group, segment) by carried counters: the four 64-bit divisions this replaces cost 700 of an item's
+  //  8000 cycles)
+  const int gstep = (int)gridDim.x;
+  const int d_seg = gstep % nseg, d_rp = (gstep / nseg) % nrp, d_b = gstep / (nseg * nrp);
+  int c_seg = (int)(blockIdx.x % nseg), c_rp = (int)((blockIdx.x / nseg) % nrp), c_b = (int)(blockIdx.x / (nseg * nrp));
+  auto setup_item = [&](long item_) {                // called for items blockIdx.x, + gridDim.x, ... in order
     const bool live = item_ < nitems;                 // past the end: every lane out of range, nothing is fetched
-    const long item = live ? item_ : 0;
-    const int seg = (int)(item % nseg);
-    const long bt = item / nseg;
-    const int t0 = ROWS * (int)(bt % nrp), b = (int)(bt / nrp);
-    const int f0 = seg * SEG;
-    const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc((void*)(dz + (size_t)b * H * W * dzs_c), 0, live ? dz_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a + (size_t)b * H * W * as_c), 0, live ? a_bytes : 0, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < NDZ; ++k) {
-      const int e = k * 512 + tid;
-      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
-      const bool ok = e < ROWS * SEG * (COUT / 8) && t0 + rr < H && f0 + p < W;
-      const unsigned off = ok ? (unsigned)((((t0 + rr) * W + f0 + p) * dzs_c + cg * 8) * 2) : OOR;
-      sdz[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdz, off, 0, 0));
+    ld_t0 = ROWS * c_rp;
+    ld_f0 = c_seg * SEG;
+    const int b = live ? c_b : 0;
+    c_seg += d_seg;
+    if (c_seg >= nseg) { c_seg -= nseg; ++c_rp; }
+    c_rp += d_rp;
+    if (c_rp >= nrp) { c_rp -= nrp; ++c_b; }
+    c_b += d_b;
+    pdz = dz + (size_t)b * H * W * dzs_c;
+    pa = a + (size_t)b * H * W * as_c;
+    live_dz = live ? dz_bytes : 0;
+    live_a = live ? a_bytes : 0;
+    if constexpr (PIPE) {
+      const unsigned long long udz = (unsigned long long)pdz, ua = (unsigned long long)pa;
+      rdz = i32x4_t{__builtin_amdgcn_readfirstlane((int)(unsigned)udz), __builtin_amdgcn_readfirstlane((int)(unsigned)(udz >> 32) & 0xffff),
+                    __builtin_amdgcn_readfirstlane((int)live_dz), 0x00020000};
+      ra = i32x4_t{__builtin_amdgcn_readfirstlane((int)(unsigned)ua), __builtin_amdgcn_readfirstlane((int)(unsigned)(ua >> 32) & 0xffff),
+                   __builtin_amdgcn_readfirstlane((int)live_a), 0x00020000};
     }
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
+  };
+  auto buf_load = [&](u32x4_t& dst, bool is_dz, unsigned off) {
+    if constexpr (PIPE) {
+      if (is_dz) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(rdz));
+      else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(ra));
+    } else {
+      const __amdgpu_buffer_rsrc_t r = is_dz ? __builtin_amdgcn_make_buffer_rsrc((void*)pdz, 0, live_dz, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, live_a, 0x00020000);
+      dst = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    }
+  };
+  auto issue_piece = [&](auto q_c) {                 // piece q of the item set up last: global -> registers
+    constexpr int q = decltype(q_c)::value;
+    if constexpr (q < NDZ) {
+      const int e = q * 512 + tid;
+      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
+      const bool ok = e < ROWS * SEG * (COUT / 8) && ld_t0 + rr < H && ld_f0 + p < W;
+      buf_load(sdz[q], true, ok ? (unsigned)((((ld_t0 + rr) * W + ld_f0 + p) * dzs_c + cg * 8) * 2) : OOR);
+    } else if constexpr (q < NP) {
+      constexpr int k = q - NDZ;
       const int e = k * 512 + tid;
       const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
-      const int tt = t0 + row - 1, ff = f0 - 1 + sl;
+      const int tt = ld_t0 + row - 1, ff = ld_f0 - 1 + sl;
       const bool ok = e < (ROWS + 2) * AW * (CIN / 8) && tt >= 0 && tt < H && ff >= 0 && ff < W;
-      const unsigned off = ok ? (unsigned)(((tt * W + ff) * as_c + cg * 8) * 2) : OOR;
-      sa[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+      buf_load(sa[k], false, ok ? (unsigned)(((tt * W + ff) * as_c + cg * 8) * 2) : OOR);
+    }
+  };
+  auto wait_loads = [&]() {                          // every piece has landed (and the compiler knows the registers changed)
+    if constexpr (PIPE) {
+      static_assert(NDZ <= 4 && NA <= 4, "operand list of the wait below");
+      if constexpr (NDZ == 2 && NA == 3)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sdz[0]), "+v"(sdz[1]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]));
+      else if constexpr (NDZ == 4 && NA == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sdz[0]), "+v"(sdz[1]), "+v"(sdz[2]), "+v"(sdz[3]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]));
+      else if constexpr (NDZ == 4 && NA == 3)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sdz[0]), "+v"(sdz[1]), "+v"(sdz[2]), "+v"(sdz[3]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]));
+      else
+        static_assert(NDZ == 0, "add the operand list for this tile shape");
     }
   };
   auto store_item = [&](int buf) {                   // registers -> LDS tiles of buffer `buf`
@@ -379,13 +436,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
     for (int k = 0; k < NDZ; ++k) {
       const int e = k * 512 + tid;
       const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
-      if (e < ROWS * SEG * (COUT / 8)) *(uint4*)(dzb + (rr * SEG + p) * DZS + cg * 16) = sdz[k];
+      if (e < ROWS * SEG * (COUT / 8)) *(u32x4_t*)(dzb + (rr * SEG + p) * DZS + cg * 16) = sdz[k];
     }
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       const int e = k * 512 + tid;
       const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
-      if (e < (ROWS + 2) * AW * (CIN / 8)) *(uint4*)(ab + (row * AW + sl) * AS + cg * 16) = sa[k];
+      if (e < (ROWS + 2) * AW * (CIN / 8)) *(u32x4_t*)(ab + (row * AW + sl) * AS + cg * 16) = sa[k];
     }
   };
 
@@ -398,8 +455,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
     const unsigned kg_a = (unsigned)(kg * NKS / (SEG / 16) * AW + (kg * NKS % (SEG / 16)) * 16) * AS;
     u32x2_t f0[PF], f1[PF];
     uint4 av = make_uint4(0u, 0u, 0u, 0u);
+    constexpr int GAP = NF / (2 * NP) < 2 ? 2 : NF / (2 * NP);       // fragment steps between two global-load pieces: all of
+    static_assert(GAP * NP <= NF, "more load pieces than fragment steps");   // them in the first half, their latency in the second
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
+      if constexpr (PIPE && s % GAP == 0 && s / GAP < NP) issue_piece(std::integral_constant<int, s / GAP>{});
       if constexpr (s < NF) {
         constexpr int j = s / 10, n = s % 10;
         constexpr int rr = j / (SEG / 16), ks = j % (SEG / 16);     // relative to the group's first k-step (NKS <= SEG/16 or KS == 1)
@@ -437,16 +497,45 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
   };
   static_assert(KS == 1 || NKS <= SEG / 16, "a k-step group stays inside one row");
 
+#ifdef DFA_STAMPS
+  long long seg_[5] = {0, 0, 0, 0, 0};
+  long long t_prev = __builtin_amdgcn_s_memtime();
+  const long long t_begin = t_prev, r_begin = __builtin_amdgcn_s_memrealtime();
+  auto stamp = [&](int k) { const long long t = __builtin_amdgcn_s_memtime(); seg_[k] += t - t_prev; t_prev = t; };
+  int n_items = 0;
+#else
+  auto stamp = [&](int) {};
+#endif
+  auto issue_all = [&]() { static_for(std::make_integer_sequence<int, NP>{}, issue_piece); };
   long item = blockIdx.x;
-  if (item < nitems) { load_item(item); store_item(0); }
+  if (item < nitems) { setup_item(item); issue_all(); wait_loads(); store_item(0); }
   __syncthreads();
+  stamp(4);
   for (int n = 0; item < nitems; item += gridDim.x, ++n) {
     const long next = item + gridDim.x;
-    load_item(next);                           // past the end: every lane out of range, nothing is fetched
-    compute(n & 1);
+    setup_item(next);                          // past the end: every lane out of range, nothing is fetched
+    if constexpr (!PIPE) issue_all();
+    stamp(0);
+    compute(n & 1);                            // (PIPE: issues the next item's pieces between its MFMAs)
+    stamp(1);
+    wait_loads();
     if (next < nitems) store_item((n + 1) & 1);
+    stamp(2);
     __syncthreads();
+    stamp(3);
+#ifdef DFA_STAMPS
+    ++n_items;
+#endif
   }
+#ifdef DFA_STAMPS
+  if (lane == 0 && blockIdx.x < 256) {
+    long long* dd = g_diag_wgrad + ((size_t)blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 5; ++k) dd[k] = seg_[k];
+    dd[5] = __builtin_amdgcn_s_memtime() - t_begin;
+    dd[6] = __builtin_amdgcn_s_memrealtime() - r_begin;
+    dd[7] = n_items;
+  }
+#endif
 
   constexpr size_t REC = (size_t)COUT * CIN * 9 + COUT;
   float* out = partial + ((size_t)blockIdx.x * KS + kg) * REC;
@@ -475,6 +564,22 @@ static hipError_t launch_wgrad_bf16_v3(const void* dz, const void* a, float* par
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), LDS, s, (const bf16_t*)dz, (const bf16_t*)a, partial, B, H, W, dzs_c, as_c);
+#ifdef DFA_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 30 && PIPE) {
+      static long long hbuf[256 * 8 * 8];
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag_wgrad), sizeof(hbuf));
+      const int nw = (nwg < 256 ? nwg : 256) * 8;
+      double m[7] = {0, 0, 0, 0, 0, 0, 0}, items = 0;
+      for (int i = 0; i < nw; ++i) { for (int k = 0; k < 7; ++k) m[k] += hbuf[i * 8 + k]; items += hbuf[i * 8 + 7]; }
+      fprintf(stderr, "[stamps wgrad v3<%d,%d,seg %d,rows %d,ks %d>] cycles per wave-item: load issue %.0f  compute %.0f  store to LDS %.0f  "
+                      "barrier %.0f  | prologue/item %.0f  lifetime/item %.0f  clock %.3f GHz  items/wave %.1f\n", CIN, COUT, SEG, ROWS, KS,
+              m[0] / items, m[1] / items, m[2] / items, m[3] / items, m[4] / items, m[5] / items, m[5] / (m[6] * 10.0), items / nw);
+    }
+  }
+#endif
   return hipGetLastError();
 }
 
@@ -534,8 +639,8 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
     const int variant = wgrad_variant();
     if (cin == 64 && cout == 128) {
       if (variant == 2) e = launch_wgrad_bf16_v2<64, 128, 32, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
-      else if (variant == 30) e = launch_wgrad_bf16_v3<64, 128, 32, 2, 1, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
-      else e = launch_wgrad_bf16_v3<64, 128, 32, 2, 1, true>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      else if (variant == 30) e = launch_wgrad_bf16_v3<64, 128, 32, 4, 1, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
+      else e = launch_wgrad_bf16_v3<64, 128, 32, 4, 1, true>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
     } else if (cin == 32 && cout == 64) {
       if (variant == 2) e = launch_wgrad_bf16_v2<32, 64, 64, true>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
       else if (variant == 30) e = launch_wgrad_bf16_v3<32, 64, 64, 4, 4, false>(dzw, aw, partial, B, H, W, nwg, s, cout_total, cin_total);
