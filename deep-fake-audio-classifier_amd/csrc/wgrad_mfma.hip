@@ -405,15 +405,18 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
     if constexpr (q < NDZ) {
       const int e = q * 512 + tid;
       const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
-      const bool ok = e < ROWS * SEG * (COUT / 8) && ld_t0 + rr < H && ld_f0 + p < W;
-      buf_load(sdz[q], true, ok ? (unsigned)((((ld_t0 + rr) * W + ld_f0 + p) * dzs_c + cg * 8) * 2) : OOR);
+      // (bitwise &, offset computed on every lane: `&&` became EXEC-masked branches inside the asm-read window)
+      const bool ok = (e < ROWS * SEG * (COUT / 8)) & (ld_t0 + rr < H) & (ld_f0 + p < W);
+      const unsigned off = (unsigned)((((ld_t0 + rr) * W + ld_f0 + p) * dzs_c + cg * 8) * 2);
+      buf_load(sdz[q], true, ok ? off : OOR);
     } else if constexpr (q < NP) {
       constexpr int k = q - NDZ;
       const int e = k * 512 + tid;
       const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
       const int tt = ld_t0 + row - 1, ff = ld_f0 - 1 + sl;
-      const bool ok = e < (ROWS + 2) * AW * (CIN / 8) && tt >= 0 && tt < H && ff >= 0 && ff < W;
-      buf_load(sa[k], false, ok ? (unsigned)(((tt * W + ff) * as_c + cg * 8) * 2) : OOR);
+      const bool ok = (e < (ROWS + 2) * AW * (CIN / 8)) & ((unsigned)tt < (unsigned)H) & ((unsigned)ff < (unsigned)W);
+      const unsigned off = (unsigned)(((tt * W + ff) * as_c + cg * 8) * 2);
+      buf_load(sa[k], false, ok ? off : OOR);
     }
   };
   auto wait_loads = [&]() {                          // every piece has landed (and the compiler knows the registers changed)
@@ -446,6 +449,30 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
     }
   };
 
+  // PIPE: the pieces are also WRITTEN to the other LDS buffer inside the MFMA stream (last quarter of the item), so the only
+  // serial part of an item is its barrier.  The other buffer was last read in the previous item, behind that item's barrier;
+  // piece q has landed once vmcnt <= NP-1-q (loads return in order).  Lanes past the end of a tile write to a spare 1 KiB
+  // behind the two buffers instead of branching (the transposed reads need EXEC all ones and no branch in their window).
+  const unsigned lds_dummy = lds0 + 2 * BUF_BYTES + lane * 16;
+  auto write_piece = [&sdz, &sa, lds0, lds_dummy, tid](auto q_c, int buf) {
+    constexpr int q = decltype(q_c)::value;
+    const unsigned base = lds0 + buf * BUF_BYTES;
+    if constexpr (q < NDZ) {
+      const int e = q * 512 + tid;
+      const int cg = e % (COUT / 8), p = (e / (COUT / 8)) % SEG, rr = e / ((COUT / 8) * SEG);
+      const unsigned addr = e < ROWS * SEG * (COUT / 8) ? base + (rr * SEG + p) * DZS + cg * 16 : lds_dummy;
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sdz[q]) : "n"(NP - 1 - q));
+      asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(sdz[q]) : "memory");
+    } else {
+      constexpr int k = q - NDZ;
+      const int e = k * 512 + tid;
+      const int cg = e % (CIN / 8), sl = (e / (CIN / 8)) % AW, row = e / ((CIN / 8) * AW);
+      const unsigned addr = e < (ROWS + 2) * AW * (CIN / 8) ? base + DZ_BYTES + (row * AW + sl) * AS + cg * 16 : lds_dummy;
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sa[k]) : "n"(NP - 1 - q));
+      asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(sa[k]) : "memory");
+    }
+  };
+
   // one item: NKS k-steps x (1 dz + 9 activation fragments), pipelined PF fragments deep.  Fragment n of k-step j:
   // n = 0 -> dz, n = 1..9 -> tap n-1.  The wave's k-steps are kidx = kg*NKS + j (row kidx / (SEG/16), 16-pixel group).
   auto compute = [&](int buf) {
@@ -455,11 +482,18 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
     const unsigned kg_a = (unsigned)(kg * NKS / (SEG / 16) * AW + (kg * NKS % (SEG / 16)) * 16) * AS;
     u32x2_t f0[PF], f1[PF];
     uint4 av = make_uint4(0u, 0u, 0u, 0u);
-    constexpr int GAP = NF / (2 * NP) < 2 ? 2 : NF / (2 * NP);       // fragment steps between two global-load pieces: all of
-    static_assert(GAP * NP <= NF, "more load pieces than fragment steps");   // them in the first half, their latency in the second
+    // PIPE schedule of the next item's NP pieces over the NF fragment steps: global loads at steps 0, G, 2G, .. (first quarter),
+    // LDS writes at steps W0, W0+G, .. (last quarter); a write at step t goes out in front of step t's fragment reads, so the
+    // counted lgkmcnt wait of fragment c at step s also counts the writes of steps c+1 .. s
+    constexpr int G = NF / (4 * NP) < 1 ? 1 : NF / (4 * NP);
+    constexpr int W0 = NF - NP * G;
+    static_assert(2 * NP * G <= NF, "loads and writes of the pieces overlap");
+    auto is_wstep = [](int t) constexpr { return t >= W0 && t < NF && (t - W0) % G == 0; };
+    const int nbuf = buf ^ 1;
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
-      if constexpr (PIPE && s % GAP == 0 && s / GAP < NP) issue_piece(std::integral_constant<int, s / GAP>{});
+      if constexpr (PIPE && s % G == 0 && s / G < NP) issue_piece(std::integral_constant<int, s / G>{});
+      if constexpr (PIPE && is_wstep(s)) write_piece(std::integral_constant<int, (s - W0) / G>{}, nbuf);
       if constexpr (s < NF) {
         constexpr int j = s / 10, n = s % 10;
         constexpr int rr = j / (SEG / 16), ks = j % (SEG / 16);     // relative to the group's first k-step (NKS <= SEG/16 or KS == 1)
@@ -477,12 +511,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
       if constexpr (s >= PF - 1) {
         constexpr int c = s - (PF - 1);
         constexpr int n = c % 10;
-        constexpr int young = 2 * ((NF - 1 - c) < (PF - 1) ? (NF - 1 - c) : (PF - 1));
+        constexpr int nw = []() constexpr { int k = 0; for (int t = c + 1; t <= s; ++t) k += (t >= W0 && t < NF && (t - W0) % G == 0) ? 1 : 0; return k; }();
+        constexpr int young = 2 * ((NF - 1 - c) < (PF - 1) ? (NF - 1 - c) : (PF - 1)) + nw;
+        static_assert(young <= 15, "lgkmcnt is a 4-bit counter");
         if constexpr (PIPE) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0[c % PF]), "+v"(f1[c % PF]) : "n"(young));
         const uint4 fv = make_uint4(f0[c % PF][0], f0[c % PF][1], f1[c % PF][0], f1[c % PF][1]);
         if constexpr (n == 0) {
           av = fv;
-          if (is == 0) {
+          {   // every wave sums its dz fragment (only the ci-slice-0 waves write the result): a wave-uniform `if` here is a
+              // branch inside the asm-read window, and the compiler is free to lay its block out of line
             const unsigned u[4] = {fv.x, fv.y, fv.z, fv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) dbsum += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
@@ -516,10 +553,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
     setup_item(next);                          // past the end: every lane out of range, nothing is fetched
     if constexpr (!PIPE) issue_all();
     stamp(0);
-    compute(n & 1);                            // (PIPE: issues the next item's pieces between its MFMAs)
+    compute(n & 1);                            // (PIPE: loads the next item's pieces and writes them to the other buffer on the way)
     stamp(1);
-    wait_loads();
-    if (next < nitems) store_item((n + 1) & 1);
+    if constexpr (PIPE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm LDS writes, which the compiler does not count
+    } else {
+      wait_loads();
+      if (next < nitems) store_item((n + 1) & 1);
+    }
     stamp(2);
     __syncthreads();
     stamp(3);
@@ -555,7 +596,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
 template <int CIN, int COUT, int SEG, int ROWS, int KS, bool PIPE>
 static hipError_t launch_wgrad_bf16_v3(const void* dz, const void* a, float* partial, int B, int H, int W, int nwg,
                                        hipStream_t s, int dzs_c, int as_c) {
-  constexpr int LDS = 2 * (ROWS * SEG * wg_stride(COUT) + (ROWS + 2) * (SEG + 2) * wg_stride(CIN));
+  constexpr int LDS = 2 * (ROWS * SEG * wg_stride(COUT) + (ROWS + 2) * (SEG + 2) * wg_stride(CIN)) + 1024;   // + spare write slots
+  static_assert(LDS <= 160 * 1024, "LDS of a CU");
   auto kern = wgrad3x3_bf16_v3_kernel<CIN, COUT, SEG, ROWS, KS, PIPE>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -32,6 +32,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+VMC = re.compile(r"vmcnt\((\d+)\)")
+VMEM_OPS = ("buffer_load", "global_load", "scratch_load", "buffer_store", "global_store", "scratch_store", "buffer_atomic",
+            "global_atomic", "flat_")
 
 
 def regs_of(text):
@@ -59,10 +62,11 @@ def check_asm(text):
     """returns (kernels checked, asm reads seen, list of violations)"""
     violations, kernels, nreads = [], 0, 0
     kernel, queue, in_asm, labels = None, [], False, set()   # queue: issue-ordered LDS ops, entries = (is_asm_read, dest regs, line no)
+    vqueue = []   # issue-ordered vector-memory ops (vmcnt retires them in order): (is_asm_load, dest regs, line no)
     for ln, raw in enumerate(text.split("\n"), 1):
         line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
         if raw.startswith("_Z") and raw.rstrip().split(";")[0].rstrip().endswith(":"):
-            kernel, queue, labels = raw.split(":")[0], [], set()
+            kernel, queue, vqueue, labels = raw.split(":")[0], [], [], set()
             kernels += 1
             continue
         if kernel is None or not line:
@@ -77,15 +81,22 @@ def check_asm(text):
             kernel = None
             continue
         inflight = set().union(*[q[1] for q in queue if q[0]]) if queue else set()
+        vinflight = set().union(*[q[1] for q in vqueue if q[0]]) if vqueue else set()
         if line.endswith(":"):                      # label: a forward skip lands here, the linear scan covers both paths
             labels.add(line[:-1])
             continue
         if line.startswith("s_cbranch") or line.startswith("s_branch"):
             if inflight and line.split()[-1] in labels:   # backward branch (loop): nothing may be in flight
                 violations.append((kernel, ln, "asm LDS read in flight across a loop back-edge: " + line))
+            if vinflight and line.split()[-1] in labels:
+                violations.append((kernel, ln, "asm buffer load in flight across a loop back-edge: " + line))
             continue
         m = LGKM.search(line)
         if line.startswith("s_waitcnt"):
+            mv = VMC.search(line)
+            if mv:
+                n = int(mv.group(1))
+                vqueue = vqueue[len(vqueue) - n:] if n else []
             if m:
                 n = int(m.group(1))
                 queue = queue[len(queue) - n:] if n < len(queue) else queue
@@ -95,6 +106,19 @@ def check_asm(text):
         if line.startswith("s_barrier"):
             continue
         touched = regs_of(line)
+        if in_asm and line.startswith("buffer_load"):     # asm global -> register load (wgrad_mfma.hip): same contract, on vmcnt
+            dest = regs_of(line.split(",")[0])
+            if dest & (vinflight | inflight):
+                violations.append((kernel, ln, "asm buffer load overwrites an in-flight destination: " + line))
+            if (regs_of(",".join(line.split(",")[1:])) & (vinflight | inflight)):
+                violations.append((kernel, ln, "asm buffer load reads an in-flight destination: " + line))
+            vqueue.append((True, dest, ln))
+            nreads += 1
+            continue
+        if touched & vinflight:
+            violations.append((kernel, ln, "touches an in-flight buffer-load destination: " + line))
+        if line.startswith(VMEM_OPS):
+            vqueue.append((False, set(), ln))
         if in_asm and line.startswith("ds_read"):
             dest = regs_of(line.split(",")[0])
             if dest & inflight:
