@@ -227,6 +227,32 @@ def test_pipelined_lds_reads_are_never_touched_in_flight():
     assert nmfma > 10000 and flagged_known >= 1
 
 
+def test_checker_flags_a_touched_in_flight_buffer_load():
+    """Positive and negative control of the checker's vector-memory rule on hand-written assembly: the destination of an asm
+    buffer load may not be read before the s_waitcnt vmcnt(N) that retires it (loads return in order), nor be in flight over a
+    loop back-edge."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_lds_pipeline", os.path.join(root, "tools", "check_lds_pipeline.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+
+    def kernel(body):
+        return "_Z1kv:\n" + "\n".join("\t" + l for l in body) + "\n\ts_endpgm\n"
+
+    load = lambda lo, hi: [";;#ASMSTART", "buffer_load_dwordx4 v[%d:%d], v1, s[4:7], 0 offen" % (lo, hi), ";;#ASMEND"]
+    wait = lambda n: [";;#ASMSTART", "s_waitcnt vmcnt(%d)" % n, ";;#ASMEND"]
+    good = load(10, 13) + load(14, 17) + ["v_add_u32_e32 v2, v3, v4"] + wait(1) + ["ds_write_b128 v5, v[10:13]"] + wait(0) + \
+        ["ds_write_b128 v5, v[14:17]"]
+    assert chk.check_asm(kernel(good))[2] == []
+    early = load(10, 13) + load(14, 17) + wait(1) + ["ds_write_b128 v5, v[14:17]"]        # the second load is still in flight
+    assert any("in-flight buffer-load" in v[2] for v in chk.check_asm(kernel(early))[2])
+    copied = load(10, 13) + ["v_mov_b32_e32 v20, v11"] + wait(0)                            # the compiler copying a stale register
+    assert any("in-flight buffer-load" in v[2] for v in chk.check_asm(kernel(copied))[2])
+    looped = [".LBB0_1:"] + load(10, 13) + ["s_cbranch_vccnz .LBB0_1"] + wait(0)
+    assert any("back-edge" in v[2] for v in chk.check_asm(kernel(looped))[2])
+
+
 def test_m16_swizzle_is_conflict_free():
     """conv3_m16.hip stores chunk c of pixel slot s at physical chunk c ^ (s & 6).  gfx950 services a ds_read_b128 in
     four fixed groups of 16 lanes; within a group the 16 x 16-byte accesses must fall in 16 distinct bank quads
