@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
   }
 
 #ifdef DFA_STAMPS
-  if (lane == 0 && blockIdx.x < 2048 && EPI == EPI_MEAN_T) {
+  if (lane == 0 && blockIdx.x < 2048 && (EPI == EPI_MEAN_T || STATS)) {
     long long* d = g_diag + ((size_t)blockIdx.x * 4 + (wave & 3)) * 8;
     for (int k = 0; k < 6; ++k) d[k] = seg[k];
     d[6] = t_begin;
@@ -624,9 +624,9 @@ hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
   dim3 grid(a.B * a.nstrips, a.COUT / (NSL * 32), 1), block(C::NT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, C::LDS_BYTES, stream, a);
 #ifdef DFA_STAMPS
-  if (EPI == EPI_MEAN_T && sizeof(T) == 2) {
+  if ((EPI == EPI_MEAN_T || STATS) && sizeof(T) == 2) {
     static int calls = 0;
-    if (++calls == 40) {
+    if (++calls == 30) {
       static long long hbuf[2048 * 4 * 8];
       hipDeviceSynchronize();
       hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_diag), sizeof(hbuf));
@@ -634,8 +634,8 @@ hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
       double m[8] = {0}; long long tmin = hbuf[6], tmax = hbuf[7];
       for (int i = 0; i < nw; ++i) { for (int k = 0; k < 6; ++k) m[k] += hbuf[i * 8 + k]; m[6] += hbuf[i * 8 + 7] - hbuf[i * 8 + 6];
         if (hbuf[i * 8 + 6] < tmin) tmin = hbuf[i * 8 + 6]; if (hbuf[i * 8 + 7] > tmax) tmax = hbuf[i * 8 + 7]; }
-      fprintf(stderr, "[stamps] waves %d  mean cycles/wave: stage_issue %.0f  mfma_loop %.0f  epilogue %.0f  vmcnt_wait %.0f  barrier %.0f  prologue %.0f  lifetime %.0f  kernel span %lld\n",
-              nw, m[0] / nw, m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw, m[6] / nw, tmax - tmin);
+      fprintf(stderr, "[stamps conv3x3<cin %d, epi %d, stats %d>] waves %d  mean cycles/wave: stage_issue %.0f  mfma_loop %.0f  epilogue %.0f  vmcnt_wait %.0f  barrier %.0f  prologue %.0f  lifetime %.0f  kernel span %lld\n",
+              CIN, EPI, (int)STATS, nw, m[0] / nw, m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw, m[6] / nw, tmax - tmin);
     }
   }
 #endif
