@@ -479,18 +479,28 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
       const bool r0ok = col_ok && t0 < H, r1ok = col_ok && t0 + 1 < H;
       float v0[16], v1[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        v0[i] = a.relu ? relu1(acc0[i], rlim) : acc0[i];
-        v1[i] = a.relu ? relu1(acc1[i], rlim) : acc1[i];
+      for (int i = 0; i < 16; ++i) {     // (the statistics forms are pre-BatchNorm outputs: never a ReLU, launcher-checked)
+        v0[i] = (!STATS && a.relu) ? relu1(acc0[i], rlim) : acc0[i];
+        v1[i] = (!STATS && a.relu) ? relu1(acc1[i], rlim) : acc1[i];
       }
       if (STATS) {
-        // selects, not 0/1 multipliers: a masked lane's accumulators are products of whatever its LDS slots held; with operands
-        // that are not staged zeros (tried: 30-column strips, whose two spare lanes read past the ring) 0 * NaN poisons the sums
+        // Per-lane sums over the rows this lane's COLUMN walks; whether the column counts is a property of the lane, applied
+        // once in front of the cross-lane reduction below (a select, so whatever a masked lane accumulated -- its operands
+        // are staged zeros here, but were stray LDS bytes in the 30-column experiment -- cannot reach a sum).  Rows past
+        // the image are wave-uniform.  4 VALU operations per element pair instead of 7: this epilogue was as long as the
+        // unit's 18 MFMAs.
+        if (t0 + 1 < H) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float u0 = r0ok ? v0[i] : 0.f, u1 = r1ok ? v1[i] : 0.f;
-          st1[i] += u0 + u1;
-          st2[i] += u0 * u0 + u1 * u1;
+          for (int i = 0; i < 16; ++i) {
+            st1[i] += v0[i] + v1[i];
+            st2[i] = fmaf(v0[i], v0[i], fmaf(v1[i], v1[i], st2[i]));
+          }
+        } else if (t0 < H) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            st1[i] += v0[i];
+            st2[i] = fmaf(v0[i], v0[i], st2[i]);
+          }
         }
       }
       T* o0 = (T*)a.out + (((size_t)b * H + t0) * W + col) * COUT + nb;
@@ -570,6 +580,8 @@ __global__ __launch_bounds__(64 * NSL * MG, MINW) void conv3x3_mfma_kernel(ConvA
     // per-channel sums: reduce over the 32 pixel lanes of each half-wave, then over the M groups through LDS
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+      st1[i] = col_ok ? st1[i] : 0.f;       // lanes whose column lies outside the image (or the strip) do not count
+      st2[i] = col_ok ? st2[i] : 0.f;
 #pragma unroll
       for (int off = 16; off > 0; off >>= 1) {
         st1[i] += __shfl_xor(st1[i], off, 64);
@@ -614,6 +626,7 @@ hipError_t launch_conv3x3(const ConvArgs& a0, hipStream_t stream) {
   using C = ConvCfg<T, CIN, NSL, MG, RP, EPI>;
   ConvArgs a = a0;
   a.nstrips = (a.W + 31) / 32;
+  if (STATS && a.relu) return hipErrorInvalidValue;     // the statistics forms store pre-BatchNorm outputs
   auto kern = conv3x3_mfma_kernel<T, CIN, NSL, MG, RP, MT, EPI, MINW, ACCIN, DMA, STATS, PFD>;
   static bool attr_set = false;
   if (!attr_set) {
