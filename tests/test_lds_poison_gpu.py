@@ -131,7 +131,7 @@ def test_cnn1d_and_cae_training_ignore_stale_lds(which):
     from dfa_amd.model_cnn1d import CNN1D
     from dfa_amd.model_cae import ConvAutoencoder
 
-    def run(pattern):
+    def run(pattern, ws_byte=None):
         torch.manual_seed(13)
         if which == "cnn1d":
             m = CNN1D(in_features=180, dropout=0.0).to("cuda").train()
@@ -140,6 +140,8 @@ def test_cnn1d_and_cae_training_ignore_stale_lds(which):
         else:
             m = ConvAutoencoder(precision=which[4:]).to("cuda").train()
             x = torch.randn(4, 64, 180, generator=torch.Generator().manual_seed(9)).to("cuda")
+        if ws_byte is not None:       # a hostile (NaN-pattern) workspace, larger than any of these shapes needs
+            m._train_ws = torch.full((192 << 20,), ws_byte, dtype=torch.uint8, device="cuda")
         if pattern is not None:
             _poison(pattern)
         if which == "cnn1d":
@@ -154,3 +156,5 @@ def test_cnn1d_and_cae_training_ignore_stale_lds(which):
     for pat in PATTERNS:
         for u, v in zip(run(pat), want):
             assert torch.equal(u, v), hex(pat)
+    for u, v in zip(run(None, 0xFF), want):
+        assert torch.equal(u, v), "workspace"
