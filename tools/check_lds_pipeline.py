@@ -47,11 +47,23 @@ def regs_of(text):
     return out
 
 
+def per_file_flags(path):
+    """the FLAGS_<file stem> := ... line of the Makefile next to the source, so the checked code is the shipped code"""
+    mk = os.path.join(os.path.dirname(os.path.abspath(path)), "Makefile")
+    stem = os.path.splitext(os.path.basename(path))[0]
+    if os.path.exists(mk):
+        for line in open(mk):
+            m = re.match(r"FLAGS_%s\s*:?=\s*(.*)" % re.escape(stem), line)
+            if m:
+                return m.group(1).split()
+    return []
+
+
 def compile_to_asm(path):
     with tempfile.NamedTemporaryFile(suffix=".s", delete=False) as f:
         out = f.name
     cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(os.path.abspath(path)), "-o", out, path]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(os.path.abspath(path))] + per_file_flags(path) + ["-o", out, path]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = open(out).read()
     os.unlink(out)
