@@ -50,7 +50,7 @@ static __device__ long long g_diag16[4096 * 2];
 template <bool PIPE, bool TRAIN = false>
 __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   using namespace m16;
-  constexpr int PF = TRAIN ? 2 : 4;      // fragment reads in flight (the train epilogue needs the registers)
+  constexpr int PF = 4;                  // fragment reads in flight (train form: 2 -> 4 was worth 2 % once the file was built without SLP)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
