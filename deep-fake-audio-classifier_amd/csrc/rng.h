@@ -1,4 +1,4 @@
-// rng.h -- counter-based Philox4x32-10 for the dropout masks (src/model.py:19,25 nn.Dropout in train mode).
+// rng.h -- counter-based Philox4x32 for the dropout masks (src/model.py:19,25 nn.Dropout in train mode).
 // The mask of element `idx` of dropout layer `layer` is a pure function of (seed, offset, layer, idx), so the backward
 // pass regenerates it instead of storing it.  torch's CPU generator stream cannot be reproduced on a GPU; parity for
 // training is exact only with dropout = 0 and statistical otherwise (SURVEY.md section 7 "hard parts").
@@ -8,9 +8,13 @@
 
 namespace dfa {
 
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+// R rounds.  The dropout masks use 7 -- the fewest rounds at which Philox4x32 passes BigCrush (Salmon et al., SC'11, table 2);
+// the standard 10 are a safety margin the masks do not need, and the rounds are quarter-rate integer multiplies that bound the
+// data-gradient kernel carrying block 1's mask in its epilogue (one call per 16-byte store).  The augmentation noise keeps 10.
+template <int R>
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < R; ++r) {
     const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
     const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
     c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
@@ -19,6 +23,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
   }
   return c;
 }
+
+constexpr int kDropRounds = 7;
 
 struct DropCfg {
   unsigned thresh;   // drop when r < thresh (thresh = p * 2^32); 0 disables dropout
@@ -40,7 +46,7 @@ __device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, floa
   }
   const uint64_t q = (idx >> 3) + d.offset;
   const uint2 key = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
-  const uint4 r0 = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
+  const uint4 r0 = philox4x32<kDropRounds>(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
   const unsigned t16 = d.thresh >> 16;
   const unsigned r[4] = {r0.x, r0.y, r0.z, r0.w};
 #pragma unroll
@@ -55,7 +61,7 @@ __device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, floa
 __device__ __forceinline__ void drop_keep8(const DropCfg& d, uint64_t idx, unsigned* km) {
   const uint64_t q = (idx >> 3) + d.offset;
   const uint2 key = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
-  const uint4 r0 = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
+  const uint4 r0 = philox4x32<kDropRounds>(make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u), key);
   const unsigned t16 = d.thresh >> 16;
   const unsigned r[4] = {r0.x, r0.y, r0.z, r0.w};
 #pragma unroll
@@ -79,7 +85,7 @@ struct AugCfg {
 
 __device__ __forceinline__ float aug_noise(const AugCfg& a, uint64_t idx) {
   const uint64_t q = idx + a.offset;
-  const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), 0x41554721u, 0u),
+  const uint4 r = philox4x32<10>(make_uint4((unsigned)q, (unsigned)(q >> 32), 0x41554721u, 0u),
                                 make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32)));
   const float u0 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
   return sqrtf(-2.0f * __logf(u0)) * __cosf(6.28318530717958648f * u1) * a.std;   // Box-Muller, one normal per element
