@@ -633,3 +633,55 @@ def test_full_size_train_steps_are_bit_reproducible(prec):
     for u, v in zip(a, b):
         assert torch.equal(u, v)
     assert torch.isfinite(a[0]).all() and torch.isfinite(a[2]).all()
+
+
+@pytest.mark.parametrize("p_drop", [0.2, 0.5])
+def test_dropout_mask_statistics(p_drop):
+    """The masks come from 7 Philox4x32 rounds, eight 16-bit uniforms per call (csrc/rng.h).  Observed in place: with BatchNorm
+    shifted far into the positive range no ReLU ever clips, so a zero in the stored block-1 / block-2 activations is a dropped
+    element.  Keep fraction within 5 sigma of 1 - p for the whole tensor, for each of the eight lanes of a call and for each
+    channel; no correlation between neighbours in any direction; a new call draws a new, equally distributed mask."""
+    from dfa_amd.model import CNN2D
+    from dfa_amd.training.train_step import cnn2d_forward_train_raw
+    B, T, F = 8, 64, 180
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, F, T, generator=gen) * 3.2).to("cuda").to(torch.bfloat16).transpose(1, 2)
+    torch.manual_seed(2)
+    m = CNN2D(in_features=F, dropout=p_drop, precision="bf16").to("cuda").train()
+    with torch.no_grad():
+        for i in m._BN_IDX:
+            m.conv[i].weight.fill_(0.05)
+            m.conv[i].bias.fill_(4.0)
+    H1, H2 = T // 2, T // 4
+    n1, nz2, n2 = B * H1 * F * 32, B * H1 * F * 64, B * H2 * F * 64
+    al = lambda v: (v + 255) // 256 * 256
+    masks = []
+    for call in range(2):
+        _, _, ws = cnn2d_forward_train_raw(m, x)
+        a1 = ws[:2 * n1].view(torch.bfloat16).view(B, H1, F, 32).float()
+        o2 = al(2 * n1) + al(2 * nz2)
+        a2 = ws[o2:o2 + 2 * n2].view(torch.bfloat16).view(B, H2, F, 64).float()
+        for a in (a1, a2):
+            assert torch.isfinite(a).all() and float(a.max()) > 0
+            keep = (a != 0).float()
+            n = keep.numel()
+            sig = (p_drop * (1 - p_drop) / n) ** 0.5
+            assert abs(float(keep.mean()) - (1 - p_drop)) < 5 * sig, (call, float(keep.mean()))
+            # kept values carry the 1 / (1 - p) scale: every kept value is at least (4 - small) / (1 - p)
+            assert float(a[a != 0].min()) > 3.0 / (1 - p_drop) * 0.9
+            flat = keep.view(-1, 8)                                    # the eight lanes of one call
+            sig8 = (p_drop * (1 - p_drop) / flat.shape[0]) ** 0.5
+            assert float((flat.mean(0) - (1 - p_drop)).abs().max()) < 5 * sig8
+            per_c = keep.mean((0, 1, 2))
+            sigc = (p_drop * (1 - p_drop) / (n / keep.shape[-1])) ** 0.5
+            assert float((per_c - (1 - p_drop)).abs().max()) < 5 * sigc
+            k0 = keep - keep.mean()
+            var = float((k0 * k0).mean())
+            for d, sl_a, sl_b in ((3, k0[..., 1:], k0[..., :-1]), (2, k0[:, :, 1:], k0[:, :, :-1]), (1, k0[:, 1:], k0[:, :-1]),
+                                  (0, k0[1:], k0[:-1])):
+                corr = float((sl_a * sl_b).mean()) / var
+                assert abs(corr) < 6.0 / sl_a.numel() ** 0.5, (d, corr)
+            masks.append(keep)
+    same1 = float((masks[0] == masks[2]).float().mean())              # two calls: agreement of independent Bernoulli masks
+    want = p_drop ** 2 + (1 - p_drop) ** 2
+    assert abs(same1 - want) < 0.01, (same1, want)
