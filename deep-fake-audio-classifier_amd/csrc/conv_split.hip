@@ -169,6 +169,22 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     constexpr int S_BAR = 4;
     constexpr bool INBAR = EPI != SPLIT_EPI_PLAIN_BF16;
     u32x4_t xbuf[PF];
+    // The 32 <- 64 data gradient carries block 1's dropout mask (a.drop): its two Philox calls per lane are index-only work, so
+    // they stand INSIDE the MFMA stream (a quarter and a half of the way in) instead of in the epilogue, where both waves of a
+    // SIMD ran them at the same time with the matrix pipe idle.  Branch-free: a zero threshold yields all-ones masks.
+    constexpr bool MASK_IN_STREAM = EPI == SPLIT_EPI_PLAIN_BF16 && CIN == 64 && NW == 2;
+    unsigned km[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};
+    uint4 rc[2];
+    uint2 rk[2];
+    // output element index of this lane's 16-byte store of row t0 + r: the row part is wave-uniform (scalar multiplies), the
+    // lane part a constant of the kernel -- written as one product chain it was ~19 quarter-rate vector multiplies per unit
+    const size_t lane_oi = (size_t)(f0 + 16 * (q & 1) + p) * COUT + 16 * wave + 8 * (q >> 1);
+    const size_t row_oi = ((size_t)b * H + t0) * ((size_t)W * COUT);
+    auto out_index = [&](int r) { return row_oi + (size_t)r * ((size_t)W * COUT) + lane_oi; };
+    auto mask_begin = [&](int r) { drop_counter(a.drop, out_index(r), rc[r], rk[r]); };
+    // one Philox round behind every second fragment read: row 0 from read R0, row 1 from read R1
+    constexpr int R0 = 4, R1 = R0 + 2 * kDropRounds + 4;
+    static_assert(R1 + 2 * kDropRounds < NR, "the rounds fit into the stream");
     auto step = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
       if constexpr (s < NR) {
@@ -176,6 +192,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         constexpr int ringrow = (BR * PH + i) % (3 * BR);
         constexpr int c0 = hl * (CPP / 2) + 4 * kk;
         xbuf[s % PF] = lds_frag<ringrow * ROWB + pb * 16 * PB, PIPE>(lds0 + (xa[dx] ^ (c0 << 4)));
+        if constexpr (MASK_IN_STREAM) {
+          if constexpr (s == R0 - 2) mask_begin(0);
+          if constexpr (s >= R0 && s < R0 + 2 * kDropRounds && (s - R0) % 2 == 0) philox_round(rc[0], rk[0]);
+          if constexpr (s == R0 + 2 * kDropRounds) drop_keep_from(a.drop, rc[0], km[0]);
+          if constexpr (s == R1 - 2) mask_begin(1);
+          if constexpr (s >= R1 && s < R1 + 2 * kDropRounds && (s - R1) % 2 == 0) philox_round(rc[1], rk[1]);
+          if constexpr (s == R1 + 2 * kDropRounds) drop_keep_from(a.drop, rc[1], km[1]);
+        }
         if constexpr (INBAR && s == S_BAR) {
           // the iteration's barrier, behind the unit's first fragment reads (rows of ring block `it`, published two barriers ago:
           // the pipeline fill overlaps the wait for the slower waves); behind it the previous unit's output stores, the LDS-DMA
@@ -237,20 +261,22 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
       }
     } else if constexpr (EPI == SPLIT_EPI_PLAIN_BF16) {
       // no activation: both rows leave as bf16, 8 consecutive channels per lane after permlane16_swap (see below)
-      const int tile = q & 1, cb = 16 * wave + 8 * (q >> 1);
+      const int tile = q & 1;
       const int col = f0 + 16 * tile + p;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const f32x4_t* acc = r ? acc1 : acc0;
         const auto d0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[1][0], acc[1][1]), false, false);
         const auto d1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(acc[0][2], acc[0][3]), pack_bf16x2(acc[1][2], acc[1][3]), false, false);
-        const size_t oi = (((size_t)b * H + t0 + r) * W + col) * COUT + cb;
+        const size_t oi = out_index(r);
         uint4 o = make_uint4(d0[0], d1[0], d0[1], d1[1]);
         pend_ok[r] = t0 + r < H && col < W && 16 * tile + p < SW;
-        if (a.drop.thresh != 0 && pend_ok[r]) {       // one Philox call per 16-byte store
-          unsigned km[4];
-          drop_keep8(a.drop, oi, km);
-          o.x &= km[0]; o.y &= km[1]; o.z &= km[2]; o.w &= km[3];
+        if constexpr (MASK_IN_STREAM) {
+          o.x &= km[r][0]; o.y &= km[r][1]; o.z &= km[r][2]; o.w &= km[r][3];
+        } else if (a.drop.thresh != 0 && pend_ok[r]) {       // one Philox call per 16-byte store
+          unsigned k4[4];
+          drop_keep8(a.drop, oi, k4);
+          o.x &= k4[0]; o.y &= k4[1]; o.z &= k4[2]; o.w &= k4[3];
         }
         pend_o[r] = o;
         pend_i[r] = oi;

@@ -11,18 +11,19 @@ namespace dfa {
 // R rounds.  The dropout masks use 7 -- the fewest rounds at which Philox4x32 passes BigCrush (Salmon et al., SC'11, table 2);
 // the standard 10 are a safety margin the masks do not need, and the rounds are quarter-rate integer multiplies that bound the
 // data-gradient kernel carrying block 1's mask in its epilogue (one call per 16-byte store).  The augmentation noise keeps 10.
+__device__ __forceinline__ void philox_round(uint4& c, uint2& k) {
+  // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: both are
+  // quarter-rate instructions, and the multiplies are what a mask costs
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+  const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+  c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+  k.x += 0x9E3779B9u;
+  k.y += 0xBB67AE85u;
+}
 template <int R>
 __device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: both are
-    // quarter-rate instructions, and the multiplies are what a mask costs
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
-    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u;
-    k.y += 0xBB67AE85u;
-  }
+  for (int r = 0; r < R; ++r) philox_round(c, k);
   return c;
 }
 
@@ -60,6 +61,19 @@ __device__ __forceinline__ void drop_scale8(const DropCfg& d, uint64_t idx, floa
 
 // the same draw as drop_scale8 as AND-masks over packed bf16 pairs: km[j] covers elements 2j (low half) and 2j+1 (high half),
 // all ones where the element is kept
+// (the same draw in pieces, for callers that spread the rounds between other work: counter / key, kDropRounds x
+//  philox_round, then drop_keep_from)
+__device__ __forceinline__ void drop_counter(const DropCfg& d, uint64_t idx, uint4& c, uint2& k) {
+  const uint64_t q = (idx >> 3) + d.offset;
+  k = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
+  c = make_uint4((unsigned)q, (unsigned)(q >> 32), d.layer, 0u);
+}
+__device__ __forceinline__ void drop_keep_from(const DropCfg& d, const uint4& r0, unsigned* km) {
+  const unsigned t16 = d.thresh >> 16;
+  const unsigned r[4] = {r0.x, r0.y, r0.z, r0.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) km[j] = (((r[j] & 0xffffu) < t16) ? 0u : 0x0000ffffu) | (((r[j] >> 16) < t16) ? 0u : 0xffff0000u);
+}
 __device__ __forceinline__ void drop_keep8(const DropCfg& d, uint64_t idx, unsigned* km) {
   const uint64_t q = (idx >> 3) + d.offset;
   const uint2 key = make_uint2((unsigned)d.seed, (unsigned)(d.seed >> 32));
