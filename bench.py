@@ -43,22 +43,46 @@ BLOCK3_FLOPS_PER_UTT = 2 * 1_061_683_200  # Conv2d 64->128 on (80,180): the domi
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
 
 
-def pmc_traffic(prec):
-    """HBM bytes per launch of the block-3 kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json for
-    the bf16 / bf16x3 kernels at HEAD, made by tools/pmc_traffic_json.py from separate --pmc runs of tools/gpu_prof_fwd.py;
-    the fp32 kernel is unchanged since round 1 and keeps profiles/r01_pmc_traffic.json).  Hardware counters cannot be read
-    from inside this process.  None if no summary holds the kernel."""
-    tag = {"bf16": "conv3_m16_meant_kernel<true, false>", "fp32": "conv3x3_mfma_kernel<float, 64, 4",
-           "bf16x3": "conv_split_kernel<64, 8, 1"}[prec]
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")    # newest first; the file used is named in the JSON line
+PMC_TAGS = {"bf16": "conv3_m16_meant_kernel<true, false>", "fp32": "conv3x3_mfma_kernel<float, 64, 4",
+            "bf16x3": "conv_split_kernel<64, 8, 1"}
+
+
+def _pmc_blob():
+    for name in PMC_FILES:
         try:
-            blob = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return name, json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        for kname, rec in blob.get("kernels", {}).items():
-            if tag in kname and rec.get("hbm_bytes_per_launch"):
-                return rec["hbm_bytes_per_launch"]
-    return None
+    return None, {}
+
+
+def pmc_kernel_traffic(tag):
+    """(HBM bytes per launch, source file) of the kernel whose name contains `tag`, from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_traffic.json, made by tools/pmc_traffic_json.py from separate --pmc runs: FETCH_SIZE x 2 + WRITE_SIZE per
+    MI355X_MICROARCH.md).  Hardware counters cannot be read from inside this process, so this is evidence about the PROFILED
+    build: the source file is named next to the number, and a kernel the newest summary does not hold gives (None, file) --
+    never a silent fall-back to an older round's file."""
+    name, blob = _pmc_blob()
+    for kname, rec in blob.get("kernels", {}).items():
+        if tag in kname and rec.get("hbm_bytes_per_launch"):
+            return rec["hbm_bytes_per_launch"], name
+    if tag == PMC_TAGS["fp32"]:           # the fp32 block-3 kernel is unchanged since round 1 and was profiled there only
+        try:
+            blob = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for kname, rec in blob.get("kernels", {}).items():
+                if tag in kname and rec.get("hbm_bytes_per_launch"):
+                    return rec["hbm_bytes_per_launch"], "r01_pmc_traffic.json"
+        except (OSError, ValueError):
+            pass
+    return None, name
+
+
+def pmc_step_traffic(step):
+    """HBM bytes of one whole step ("train_step", "cnn1d_fwd", "cae_score", ...) summed over its kernels, from the same file."""
+    name, blob = _pmc_blob()
+    rec = blob.get("steps", {}).get(step)
+    return (rec.get("hbm_bytes_per_step") if rec else None), name
 
 
 def parse_args():
@@ -70,6 +94,8 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU per step")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-train", action="store_true", help="skip the training-step leg")
+    p.add_argument("--no-other-models", action="store_true", help="skip the CNN1D / auto-encoder legs")
     p.add_argument("--small-batch", action="store_true", help="add the batch 1 / batch 32 latency leg (time-axis split on / off)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     p.add_argument("--e2e-utts", type=int, default=512, help="utterances in the end-to-end (features.pkl -> prediction.pkl) legs")
@@ -92,14 +118,37 @@ def build_model(torch, device, precision):
     return model.to(device).eval()
 
 
-def timed_steps(torch, dist, model, x, steps, warmup, world):
-    """W untimed warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize on both sides.  Inside the
-    timed region only the dominant kernel (timing slot 2) is bracketed by HIP events on the launch stream; the per-kernel
-    breakdown (every launch bracketed) runs directly AFTER the timed region -- the only host work in between is reading
-    back the <= 256 already-completed events of slot 2 -- so both are taken in the same warmed-up clock state."""
+def precondition(torch, ctx, model, x, slot=2, batch=25, tol=0.01, max_batches=40):
+    """Untimed launches until the dominant kernel's HIP-event time is stable: after an idle period the first launches run
+    ~9 % slower (clock ramp), so a short `--steps 20 --warmup 5` run would otherwise time the ramp.  Batches of `batch` forwards;
+    stops when two consecutive batch means agree within `tol` (at least 3 batches).  Returns (launches made, last mean ms)."""
+    ctx.timing_reset()
+    ctx.timing(1 << slot)
+    prev, n = None, 0
+    for i in range(max_batches):
+        for _ in range(batch):
+            model(x)
+        ms, cnt = ctx.timing_read(slot)
+        ctx.timing_reset()
+        cur = ms / max(cnt, 1)
+        n += batch
+        if prev is not None and i >= 2 and abs(cur - prev) <= tol * prev:
+            prev = cur
+            break
+        prev = cur
+    ctx.timing(False)
+    return n, prev
+
+
+def timed_steps(torch, dist, model, x, steps, warmup, world, probe_clock=False):
+    """Pre-conditioning (untimed, see precondition), W untimed warm-up steps, then EXACTLY `steps` timed steps between barrier +
+    synchronize on both sides.  Inside the timed region only the dominant kernel (timing slot 2) is bracketed by HIP events on
+    the launch stream; the per-kernel breakdown (every launch bracketed) runs directly AFTER the timed region -- the only host
+    work in between is reading back the <= 256 already-completed events of slot 2 -- so both are taken in the same clock state.
+    probe_clock: the breakdown launches also stamp s_memtime / s_memrealtime inside the dominant kernel (dfa_ctx_clock_read)."""
     from dfa_amd import _lib
     ctx = _lib.Context.get(x.device)
-    ctx.timing(False)
+    pre_n, _ = precondition(torch, ctx, model, x)
     for _ in range(warmup):
         model(x)
     ctx.timing_reset()
@@ -117,18 +166,27 @@ def timed_steps(torch, dist, model, x, steps, warmup, world):
     dominant = ctx.timing_read(2)
     ctx.timing_reset()
     ctx.timing(True)
+    if probe_clock:
+        ctx.set_option("clock_probe", 1)
     for _ in range(30):
         model(x)
     ctx.timing(False)
     torch.cuda.synchronize()
+    clock = None
+    if probe_clock:
+        med, lo, hi, n = ctx.clock_read()
+        ctx.set_option("clock_probe", 0)
+        if n:
+            clock = {"ghz": round(med, 3), "min": round(lo, 3), "max": round(hi, 3), "workgroups": n}
     slots = [ctx.timing_read(s) for s in range(4)]
     ctx.timing_reset()
+    probe_ms = slots[2][0] / max(slots[2][1], 1)
     slots[2] = dominant
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, slots, out
+    return dt, slots, out, {"precondition_launches": pre_n, "clock": clock, "probe_kernel_ms": round(probe_ms, 4)}
 
 
 def host_cores():
@@ -277,46 +335,88 @@ def small_batch_metric(torch, device, steps=200, warmup=30):
 TRAIN_FLOPS_PER_UTT = 9_621_849_600      # fwd 3.218 G + wgrad 3.218 G + dgrad(conv2,3) + linear 3.185 G
 
 
-def train_step_metric(torch, device, B, steps=20, warmup=5):
-    """Secondary metric (BASELINE configs[2]): CNN2D training step (fwd + bwd + fused AdamW, dropout 0.2, label
-    smoothing 0.05) in the bf16-storage mode, utterances/s on this rank."""
+def train_step_metric(torch, dist, device, B, world, rank, steps=20, warmup=8):
+    """BASELINE configs[2]: CNN2D training step (fwd + bwd + fused AdamW, dropout 0.2, label smoothing 0.05) in the bf16-storage
+    mode, data-parallel over `world` ranks (B utterances per rank): every step ends with the SUM all-reduce of the flat 464,644-byte
+    gradient buffer (RCCL over xGMI under the "nccl" backend; src/train.py:74-76 has no counterpart, the reference is
+    single-device) and the fused AdamW with the 1/world scale folded in.  Same barrier + max-over-ranks protocol as the headline;
+    value = GLOBAL utterances/s.  The all-reduce alone is timed separately with HIP events on the same buffer."""
     from dfa_amd.model import CNN2D
     from dfa_amd.training.train_step import NativeTrainer
     torch.manual_seed(0)
     model = CNN2D(in_features=F, dropout=0.2, precision="bf16").to(device)
-    g = torch.Generator().manual_seed(99)
+    model._drop_seed = 1234 + 7919 * rank                       # ranks draw different dropout masks (train.py mixes the rank in too)
+    g = torch.Generator().manual_seed(99 + rank)
     x = (torch.randn(B, F, T, generator=g) * 3.2 - 0.07).to(device=device, dtype=torch.bfloat16).transpose(1, 2)
     y = (torch.rand(B, generator=g) > 0.5).float().to(device)
     tr = NativeTrainer(model, label_smoothing=0.05)
     for _ in range(warmup):
         tr.step(x, y)
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(x, y)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    ach = B * TRAIN_FLOPS_PER_UTT / dt / 1e12
-    return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
-            "batch_per_gpu": B, "loss": round(float(loss.item()), 4),
-            "roofline": {"bound": "mfma", "scope": "whole step (forward + backward + AdamW), algorithmic FLOPs / wall time",
-                         "achieved": round(ach, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_TFLOPS["bf16"], 4), "flops_per_utt": TRAIN_FLOPS_PER_UTT,
-                         "traffic": None},
-            "what": "fwd + bwd + fused AdamW, dropout 0.2, label smoothing 0.05 (src/train.py:71-76), 1 GPU"}
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ar_ms = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        buf = torch.zeros_like(tr.flat_g)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 50
+    dt /= steps
+    ach = B * TRAIN_FLOPS_PER_UTT / dt / 1e12                   # per GPU
+    traffic, src = pmc_step_traffic("train_step")
+    out = {"value": round(world * B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
+           "batch_per_gpu": B, "global_batch": world * B, "n_gpus": world, "loss_rank0": round(float(loss.item()), 4),
+           "roofline": {"bound": "mfma", "scope": "whole step (forward + backward + all-reduce + AdamW), algorithmic FLOPs / wall "
+                                                   "time, per GPU",
+                        "achieved": round(ach, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_TFLOPS["bf16"], 4), "flops_per_utt": TRAIN_FLOPS_PER_UTT,
+                        "traffic": traffic if B == B_PER_GPU else None, "traffic_source": src},
+           "what": f"fwd + bwd + one flat-gradient all-reduce + fused AdamW, dropout 0.2, label smoothing 0.05 "
+                   f"(src/train.py:71-76), data-parallel x{world}"}
+    if world > 1:
+        out["allreduce"] = {"ms": round(ar_ms, 4), "bytes": tr.flat_g.numel() * 4, "backend": dist.get_backend(),
+                            "what": "SUM all-reduce of the flat fp32 gradient alone (HIP events, mean of 50)"}
+    return out
+
+
+CNN1D_BYTES_PER_UTT = 231_124            # SURVEY.md section 8(d): read x once (fp32) + 4 B out
+CNN1D_FLOPS_PER_UTT = 30_816_256
+CAE_FLOPS_PER_UTT = 1_792_021_760        # SURVEY.md section 8(d): CAE forward (+ MSE)
+CAE_TRAIN_FLOPS_PER_UTT = 3 * CAE_FLOPS_PER_UTT - 2 * 16_640_640   # fwd + wgrad + dgrad (no data gradient through encoder block 1)
 
 
 def other_models_metric(torch, device, B, steps=20, warmup=5):
-    """Secondary paths of SURVEY section 8 at the same batch (rank 0, N = 1 only): CNN1D forward (a3), the auto-encoder's
-    anomaly score with the z-score and per-sample MSE fused in (a4/a5/a13), and the auto-encoder training step."""
+    """Secondary paths of SURVEY section 8 at the same batch (rank 0, N = 1 only), each with the roofline section 8(d) assigns it:
+    CNN1D forward (a3: HBM-bound, 231,124 B per utterance), the auto-encoder's anomaly score with the z-score and per-sample MSE
+    fused in (a4/a5/a13: MFMA-bound, 1.792 GFLOP per utterance) and the auto-encoder training step."""
+    from dfa_amd import _lib
     from dfa_amd.model_cae import ConvAutoencoder
     from dfa_amd.model_cnn1d import CNN1D
+    ctx = _lib.Context.get(device)
     g = torch.Generator().manual_seed(77)
     stored = (torch.randn(B, F, T, generator=g) * 3.2 - 0.07).to(device)
     x = stored.transpose(1, 2)
 
-    def rate(fn):
-        for _ in range(warmup):
+    def rate(fn, slots=()):
+        for _ in range(warmup + 10):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -324,17 +424,78 @@ def other_models_metric(torch, device, B, steps=20, warmup=5):
             fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3)}
+        rec = {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 4)}
+        if slots:                                           # per-kernel HIP-event times of the same launches, after the timed loop
+            ctx.timing_reset()
+            ctx.timing(True)
+            for _ in range(20):
+                fn()
+            ctx.timing(False)
+            torch.cuda.synchronize()
+            rec["kernel_ms"] = {}
+            for name, sl in slots:
+                ms, n = ctx.timing_read(sl)
+                if n:
+                    rec["kernel_ms"][name] = round(ms / n, 4)
+            ctx.timing_reset()
+        return rec
 
     torch.manual_seed(0)
     out = {}
     m1 = CNN1D(in_features=F).to(device).eval()
-    out["cnn1d_fwd_fp32"] = rate(lambda: m1(x))
+    r = rate(lambda: m1(x), slots=(("conv1", 4), ("conv2", 5), ("conv3", 6), ("linear", 7)))
+    k_ms = sum(r["kernel_ms"].values()) if r.get("kernel_ms") else r["ms_per_step"]
+    gbs = B * CNN1D_BYTES_PER_UTT / (k_ms * 1e-3) / 1e9
+    traffic, src = pmc_step_traffic("cnn1d_fwd")
+    r["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                     "bytes_per_utt": CNN1D_BYTES_PER_UTT, "kernel_ms": round(k_ms, 4),
+                     "traffic": traffic if B == B_PER_GPU else None, "traffic_source": src}
+    out["cnn1d_fwd_fp32"] = r
     mean, std = torch.zeros(F, device=device), torch.ones(F, device=device)
     cae = ConvAutoencoder(precision="bf16").to(device).eval()
     x16 = x.to(torch.bfloat16)
-    out["cae_score_bf16"] = rate(lambda: cae.score(x16, mean, std))
+    r = rate(lambda: cae.score(x16, mean, std),
+             slots=(("enc1", 8), ("enc2", 9), ("enc3", 10), ("enc4", 11), ("dec1", 12), ("dec2", 13), ("dec3", 14), ("dec4_mse", 15)))
+    tf = B * CAE_FLOPS_PER_UTT / (r["ms_per_step"] * 1e-3) / 1e12
+    traffic, src = pmc_step_traffic("cae_score")
+    r["roofline"] = {"bound": "mfma", "scope": "whole score (encoder + decoder + MSE), algorithmic FLOPs / wall time",
+                     "achieved": round(tf, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_TFLOPS["bf16"], 4), "flops_per_utt": CAE_FLOPS_PER_UTT,
+                     "traffic": traffic if B == B_PER_GPU else None, "traffic_source": src}
+    out["cae_score_bf16"] = r
+    try:
+        out["cae_train_step_bf16"] = cae_train_metric(torch, device, B)
+    except Exception as e:                                   # secondary leg: report, never lose the headline line
+        out["cae_train_step_bf16"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def cae_train_metric(torch, device, B, steps=10, warmup=4):
+    """Auto-encoder training step (src/train_cae.py:58-82: recon = model(x); MSELoss(recon, x); backward; AdamW lr 1e-4 wd 1e-4) in
+    the bf16-storage mode on the flat-buffer trainer."""
+    from dfa_amd.model_cae import ConvAutoencoder
+    from dfa_amd.training.train_step import make_cae_trainer
+    torch.manual_seed(0)
+    model = ConvAutoencoder(precision="bf16").to(device).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, F, generator=g).to(device=device, dtype=torch.bfloat16)
+    tr = make_cae_trainer(model, lr=1e-4, weight_decay=1e-4)
+    for _ in range(warmup):
+        tr.step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = B * CAE_TRAIN_FLOPS_PER_UTT / dt / 1e12
+    traffic, src = pmc_step_traffic("cae_train_step")
+    return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5),
+            "trainer": type(tr).__name__,
+            "roofline": {"bound": "mfma", "scope": "whole step, algorithmic FLOPs / wall time", "achieved": round(tf, 2),
+                         "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16"], 4),
+                         "flops_per_utt": CAE_TRAIN_FLOPS_PER_UTT, "traffic": traffic if B == B_PER_GPU else None,
+                         "traffic_source": src}}
 
 
 def spawn_ranks(args):
@@ -389,24 +550,35 @@ def main():
     results = {}
     for prec, x in (("bf16", x16), ("bf16x3", x32), ("fp32", x32)):
         model = build_model(torch, device, prec)
-        dt, slots, out = timed_steps(torch, dist, model, x, args.steps, args.warmup, world)
+        dt, slots, out, extra = timed_steps(torch, dist, model, x, args.steps, args.warmup, world, probe_clock=(prec == "bf16"))
         if not torch.isfinite(out).all():
             raise SystemExit(f"non-finite logits in {prec} mode")
         ms3, n3 = slots[2]
         k_ms = ms3 / max(n3, 1)
         ach = BLOCK3_FLOPS_PER_UTT * B / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic, traffic_src = pmc_kernel_traffic(PMC_TAGS[prec])
         results[prec] = {
             "value": world * B * args.steps / dt,
             "ms_per_step": dt / args.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": BLOCK3_KERNEL[prec] + " (CNN2D block 3, 64->128, +BN+ReLU+mean_T)",
                          "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[prec], 1), "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_TFLOPS[prec], 4),
-                         "traffic": pmc_traffic(prec) if B == B_PER_GPU else None,
-                         "kernel_ms": round(k_ms, 4), "launches_timed": n3},
+                         "traffic": traffic if B == B_PER_GPU else None, "traffic_source": traffic_src,
+                         "kernel_ms": round(k_ms, 4), "launches_timed": n3,
+                         "precondition_launches": extra["precondition_launches"]},
             "kernel_ms": {name: round(ms / max(n, 1), 4) for name, (ms, n) in
                           zip(("conv1", "block2_mfma_or_fused_blocks12", "block3_mfma", "linear"), slots)},
             "logits_sample": [round(float(v), 6) for v in out[:3, 0].float().cpu()],
         }
+        if extra["clock"]:
+            # the 2500 TFLOP/s peak is quoted at 2.4 GHz; under MFMA load the chip holds less (MI355X_MICROARCH.md, DVFS give-back):
+            # clock_ghz is measured INSIDE the dominant kernel (s_memtime / s_memrealtime around its main loop, median over 1024
+            # workgroups) in the launches that directly follow the timed region, so box spread and kernel regressions separate
+            rf = results[prec]["roofline"]
+            rf["clock_ghz"] = extra["clock"]["ghz"]
+            rf["clock_ghz_min_max"] = [extra["clock"]["min"], extra["clock"]["max"]]
+            rf["frac_at_held_clock"] = round(ach / (PEAK_TFLOPS[prec] * extra["clock"]["ghz"] / 2.4), 4)
+            rf["probe_kernel_ms"] = extra["probe_kernel_ms"]
         sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         del model
 
@@ -437,10 +609,14 @@ def main():
                             "max_abs_logit_diff_vs_bf16": round(max(abs(a - b) for a, b in
                                                                     zip(r16["logits_sample"], r32["logits_sample"])), 5)},
         }
-        if world == 1:
-            if args.small_batch:      # opt-in: its B = 1 / 32 launches would mix into the per-kernel averages of a rocprofv3 run
-                line["small_batch"] = small_batch_metric(torch, device)
-            line["train_step"] = train_step_metric(torch, device, B)
+        if world == 1 and args.small_batch:   # opt-in: its B = 1 / 32 launches would mix into the per-kernel averages of a rocprofv3 run
+            line["small_batch"] = small_batch_metric(torch, device)
+    # BASELINE configs[2]: the data-parallel training step runs on EVERY rank (its all-reduce is a collective)
+    train = None if args.no_train else train_step_metric(torch, dist, device, B, world, rank)
+    if rank == 0:
+        if train is not None:
+            line["train_step"] = train
+        if world == 1 and not args.no_other_models:
             line["other_models"] = other_models_metric(torch, device, B)
         if world == 1 and not args.no_cpu_baseline:
             import tempfile

@@ -72,11 +72,15 @@ SYMBOLS = [
                                         C.c_void_p, C.c_size_t]),
     ("dfa_cae_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                    C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]),
+    ("dfa_mse_fwd_bwd", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                  C.c_int64, C.c_void_p, C.c_void_p]),
     ("dfa_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("dfa_dominant_kernel", C.c_char_p, [C.c_int, C.c_int]),
     ("dfa_ctx_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("dfa_ctx_timing_reset", C.c_int, [C.c_void_p]),
     ("dfa_ctx_timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("dfa_ctx_clock_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int)]),
 ]
 
 
@@ -190,6 +194,12 @@ class Context:
         ms, n = C.c_float(), C.c_int()
         check(self.handle, self.lib.dfa_ctx_timing_read(self.handle, slot, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def clock_read(self):
+        """(median, min, max GHz, workgroups) of the last bf16 CNN2D block-3 launch run with set_option("clock_probe", 1)."""
+        med, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        check(self.handle, self.lib.dfa_ctx_clock_read(self.handle, C.byref(med), C.byref(lo), C.byref(hi), C.byref(n)))
+        return med.value, lo.value, hi.value, n.value
 
 
 def x_dtype_code(t: torch.Tensor) -> int:

@@ -3,6 +3,8 @@
 //   conv1 (+BN+ReLU+pool)  ->  block 2 MFMA conv (+BN+ReLU+pool)  ->  block 3 MFMA conv (+BN+ReLU+mean_T)  ->  linear.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "dfa_internal.h"
 #include "trace.h"
 #include "convt2x2_mfma.h"
@@ -20,7 +22,8 @@ struct Cnn2dPlan {
   size_t a1_off, a2_off, emb_off, total;
 };
 
-Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
+// forced_split: the context's "time_split" option (> 0 forces a split whatever the batch, so the chunk slabs must exist)
+Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec, int forced_split = -1) {
   Cnn2dPlan p;
   const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;   // fp32, or a hi + lo bf16 pair (DFA_PREC_BF16X3)
   p.H1 = T / 2;
@@ -33,7 +36,7 @@ Cnn2dPlan plan_cnn2d(int B, int T, int F, int prec) {
   p.emb_off = off;
   // small batches split the time axis over up to kMaxSeg workgroups per strip: one partial embedding per segment
   const int nstrips = (F + 31) / 32;
-  const size_t nemb = ((size_t)B * nstrips < 512) ? kMaxSeg + 1 : 1;
+  const size_t nemb = (forced_split > 0 || (size_t)B * nstrips < 512) ? kMaxSeg + 1 : 1;
   off = align_up(off + nemb * (size_t)B * 128 * F * sizeof(float), 256);
   p.total = off;
   return p;
@@ -153,6 +156,8 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   if (ctx->cae.packed) (void)hipFree(ctx->cae.packed);
   if (ctx->cae.train_packed) (void)hipFree(ctx->cae.train_packed);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+  if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
+  if (ctx->mse_partial) (void)hipFree(ctx->mse_partial);
   for (auto& t : ctx->slots) {
     for (auto e : t.start) (void)hipEventDestroy(e);
     for (auto e : t.stop) (void)hipEventDestroy(e);
@@ -182,12 +187,9 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsig
   if (lds_words[(threadIdx.x * 97 + blockIdx.x) % N] != pattern) sink[0] = 1;   // keeps the stores; never true
 }
 hipError_t launch_poison_lds(dfa_ctx* ctx, unsigned half) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  hipError_t e = hipSetDevice(ctx->device);   // the attribute is per device: set it on every call (a test hook, cheap)
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
   half &= 0xffffu;
   hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, ctx->stream, half | (half << 16), (unsigned*)ctx->zero_page);
   return hipGetLastError();
@@ -203,6 +205,15 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "train_conv_variant") == 0) { set_train_conv_variant(value); return DFA_OK; }
   if (strcmp(name, "wgrad_variant") == 0) { set_wgrad_variant(value); return DFA_OK; }
   if (strcmp(name, "time_split") == 0) { ctx->time_split = value; return DFA_OK; }
+  if (strcmp(name, "clock_probe") == 0) {
+    if (value && !ctx->clock_buf) {
+      DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+      DFA_HIP_CHECK(ctx, hipMalloc((void**)&ctx->clock_buf, 1024 * 2 * sizeof(long long)));
+    }
+    if (value) DFA_HIP_CHECK(ctx, hipMemsetAsync(ctx->clock_buf, 0, 1024 * 2 * sizeof(long long), ctx->stream));
+    ctx->clock_probe = value ? 1 : 0;
+    return DFA_OK;
+  }
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
@@ -238,6 +249,29 @@ int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count) {
   }
   *total_ms = sum;
   *count = t.used;
+  return DFA_OK;
+}
+
+int dfa_ctx_clock_read(dfa_ctx* ctx, double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups) {
+  if (!ctx || !ghz_median || !workgroups) return DFA_E_NULL_PTR;
+  *ghz_median = 0.0; *workgroups = 0;
+  if (ghz_min) *ghz_min = 0.0;
+  if (ghz_max) *ghz_max = 0.0;
+  if (!ctx->clock_buf) return fail(ctx, DFA_E_NOT_PREPARED, "set the context option clock_probe = 1 and run a bf16 CNN2D forward first");
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  DFA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  static thread_local long long h[1024 * 2];
+  DFA_HIP_CHECK(ctx, hipMemcpy(h, ctx->clock_buf, sizeof(h), hipMemcpyDeviceToHost));
+  double g[1024];
+  int n = 0;
+  for (int i = 0; i < 1024; ++i)
+    if (h[2 * i + 1] > 0 && h[2 * i] > 0) g[n++] = (double)h[2 * i] / ((double)h[2 * i + 1] * 10.0);   // cycles / (ticks * 10 ns) = GHz
+  if (n == 0) return DFA_OK;
+  std::sort(g, g + n);
+  *ghz_median = g[n / 2];
+  if (ghz_min) *ghz_min = g[0];
+  if (ghz_max) *ghz_max = g[n - 1];
+  *workgroups = n;
   return DFA_OK;
 }
 
@@ -308,9 +342,8 @@ int dfa_cnn2d_prepare(dfa_ctx* ctx, int precision) {
 }
 
 size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision) {
-  (void)ctx;
   if (B < 1 || T < 1 || F < 1) return 0;
-  if (model == DFA_MODEL_CNN2D) return plan_cnn2d(B, T, F, precision).total;
+  if (model == DFA_MODEL_CNN2D) return plan_cnn2d(B, T, F, precision, ctx ? ctx->time_split : -1).total;
   if (model == DFA_MODEL_CNN1D) return plan_cnn1d(B, T).total;
   if (model == DFA_MODEL_CAE) return plan_cae(B, T, F, precision).total;
   return 0;
@@ -329,10 +362,12 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
     return fail(ctx, DFA_E_BAD_SHAPE, "feature dim %d does not match in_features=%d of the classifier (src/model.py:31)", F, m.in_features);
   if (T < 4) return fail(ctx, DFA_E_BAD_SHAPE, "T=%d is too short: two (2,1) average pools need T >= 4", T);
   const int prec = m.prepared_prec;
-  const Cnn2dPlan pl = plan_cnn2d(B, T, F, prec);
+  const Cnn2dPlan pl = plan_cnn2d(B, T, F, prec, ctx->time_split);
   if (workspace_bytes < pl.total)
     return fail(ctx, DFA_E_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
   if (((uintptr_t)workspace & 255) != 0) return fail(ctx, DFA_E_WORKSPACE, "workspace must be 256-byte aligned");
+  if (embedding && ((uintptr_t)embedding & 15) != 0)   // emb_reduce_kernel / the block-3 epilogues store 16 bytes at a time
+    return fail(ctx, DFA_E_BAD_SHAPE, "embedding must be 16-byte aligned (got %p)", (void*)embedding);
   char* ws = (char*)workspace;
   void* a1 = ws + pl.a1_off;
   void* a2 = ws + pl.a2_off;
@@ -387,6 +422,7 @@ int dfa_cnn2d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3_split(a, s, ctx->lds_pipe));
     } else if (prec == DFA_PREC_BF16 && ctx->block3_m16) {
       a.wpack = m.c3_m16;
+      a.clock_stamps = ctx->clock_probe ? ctx->clock_buf : nullptr;
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3_m16(a, s, ctx->lds_pipe));
     } else {
       DFA_HIP_CHECK(ctx, launch_cnn2d_block3(prec, a, s, ctx->conv_dma, ctx->lds_pipe));

@@ -72,11 +72,21 @@ __device__ __forceinline__ void ld32<bf16_t>(const bf16_t* p, float* v) {
 // decoder block 4 backward (ConvTranspose2d 32 -> 1): for every d3 pixel (i,j) with its 2x2 patch of drecon
 //   dd3[ci] = sum_q g_q * w4[ci][q];   dW4[ci][q] += d3[ci] * g_q;   db4 += sum_q g_q
 // Each thread walks many pixels keeping the 129 sums in registers; partial[block][132].
+// MSE form (drecon == nullptr; src/train_cae.py:67-68 loss = MSELoss(recon, x)): the upstream gradient never exists in memory --
+// g_q = mse_scale * (recon_q - x_q) with recon_q = b4 + sum_ci d3[ci] * w4[ci][q] recomputed from the d3 pixel the thread holds
+// anyway (128 FMAs) and x read through the caller's strides; mse_scale = 2 / (B*T*F).
+struct MseSrc {
+  const void* x;
+  int x_bf16;
+  int64_t sb, st, sf;
+  float b4, scale;
+  const float* b4_dev;     // device pointer to decoder.9.bias (read once per thread)
+};
 template <typename T>
 __global__ __launch_bounds__(256) void cae_dec4_bwd_kernel(const T* __restrict__ d3, const float* __restrict__ w4,
                                                            const float* __restrict__ drecon, T* __restrict__ dd3,
                                                            float* __restrict__ partial, int B, int H3, int W3, int Tt,
-                                                           int F) {
+                                                           int F, MseSrc mse) {
   __shared__ float red[4][132];
   const int tid = threadIdx.x;
   float wv[32][4];
@@ -87,19 +97,36 @@ __global__ __launch_bounds__(256) void cae_dec4_bwd_kernel(const T* __restrict__
   float acc[129];
 #pragma unroll
   for (int k = 0; k < 129; ++k) acc[k] = 0.f;
+  const float bias4 = drecon ? 0.f : mse.b4_dev[0];
   const size_t npix = (size_t)B * H3 * W3;
   for (size_t p = (size_t)blockIdx.x * 256 + tid; p < npix; p += (size_t)gridDim.x * 256) {
     const int j = (int)(p % W3);
     const size_t bi = p / W3;
     const int i = (int)(bi % H3), b = (int)(bi / H3);
     float g[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int t = 2 * i + (q >> 1), f = 2 * j + (q & 1);
-      g[q] = (t < Tt && f < F) ? drecon[((size_t)b * Tt + t) * F + f] : 0.f;
-    }
     float v[32], o[32];
     ld32<T>(d3 + p * 32, v);
+    if (drecon) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = 2 * i + (q >> 1), f = 2 * j + (q & 1);
+        g[q] = (t < Tt && f < F) ? drecon[((size_t)b * Tt + t) * F + f] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = 2 * i + (q >> 1), f = 2 * j + (q & 1);
+        float r = bias4;
+#pragma unroll
+        for (int ci = 0; ci < 32; ++ci) r = fmaf(v[ci], wv[ci][q], r);
+        float xv = 0.f;
+        if (t < Tt && f < F) {
+          const int64_t off = (int64_t)b * mse.sb + (int64_t)t * mse.st + (int64_t)f * mse.sf;
+          xv = mse.x_bf16 ? bf16_to_float(((const bf16_t*)mse.x)[off]) : ((const float*)mse.x)[off];
+        }
+        g[q] = (t < Tt && f < F) ? mse.scale * (r - xv) : 0.f;
+      }
+    }
 #pragma unroll
     for (int ci = 0; ci < 32; ++ci) {
       o[ci] = (g[0] * wv[ci][0] + g[1] * wv[ci][1]) + (g[2] * wv[ci][2] + g[3] * wv[ci][3]);
@@ -155,11 +182,65 @@ hipError_t launch_convt_q_to_w(const float* dwq, float* dw, int cin, int cout, h
 constexpr int kDec4Blocks = 512;
 int cae_dec4_bwd_blocks() { return kDec4Blocks; }
 hipError_t launch_cae_dec4_bwd(int prec, const void* d3, const float* w4, const float* drecon, void* dd3, float* partial,
-                               int B, int H3, int W3, int T, int F, hipStream_t s) {
+                               int B, int H3, int W3, int T, int F, hipStream_t s, const MseArgs* mse_args) {
+  MseSrc mse{};
+  if (!drecon) {
+    if (!mse_args) return hipErrorInvalidValue;
+    mse.x = mse_args->x; mse.x_bf16 = mse_args->x_bf16; mse.sb = mse_args->sb; mse.st = mse_args->st; mse.sf = mse_args->sf;
+    mse.b4 = 0.f; mse.scale = 2.0f / ((float)B * (float)T * (float)F);
+    mse.b4_dev = mse_args->b4_dev;
+  }
   if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(cae_dec4_bwd_kernel<bf16_t>, dim3(kDec4Blocks), dim3(256), 0, s, (const bf16_t*)d3, w4, drecon, (bf16_t*)dd3, partial, B, H3, W3, T, F);
+    hipLaunchKernelGGL(cae_dec4_bwd_kernel<bf16_t>, dim3(kDec4Blocks), dim3(256), 0, s, (const bf16_t*)d3, w4, drecon, (bf16_t*)dd3, partial, B, H3, W3, T, F, mse);
   else
-    hipLaunchKernelGGL(cae_dec4_bwd_kernel<float>, dim3(kDec4Blocks), dim3(256), 0, s, (const float*)d3, w4, drecon, (float*)dd3, partial, B, H3, W3, T, F);
+    hipLaunchKernelGGL(cae_dec4_bwd_kernel<float>, dim3(kDec4Blocks), dim3(256), 0, s, (const float*)d3, w4, drecon, (float*)dd3, partial, B, H3, W3, T, F, mse);
+  return hipGetLastError();
+}
+// MSELoss(recon, x) forward + backward in one pass (src/train_cae.py:67-68, criterion at :203): every block sums its squared
+// differences in a fixed order and writes drecon = 2 (recon - x) / n; a second one-block launch adds the block sums in index order.
+__global__ __launch_bounds__(256) void mse_fwd_bwd_kernel(const float* __restrict__ recon, const void* __restrict__ x, int x_bf16,
+                                                          int64_t sb, int64_t st, int64_t sf, int T, int F, size_t n, float scale,
+                                                          float* __restrict__ partial, float* __restrict__ drecon) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  const size_t per = (n + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (size_t i = lo + tid; i < hi; i += 256) {
+    const int f = (int)(i % F);
+    const size_t bt = i / F;
+    const int t = (int)(bt % T);
+    const int64_t b = (int64_t)(bt / T);
+    const int64_t off = b * sb + (int64_t)t * st + (int64_t)f * sf;
+    const float xv = x_bf16 ? bf16_to_float(((const bf16_t*)x)[off]) : ((const float*)x)[off];
+    const float d = recon[i] - xv;
+    acc = fmaf(d, d, acc);
+    if (drecon) drecon[i] = scale * d;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict__ partial, int nblk, double inv_n, float* __restrict__ loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] * inv_n);
+}
+hipError_t launch_mse_fwd_bwd(const float* recon, const void* x, int x_bf16, int64_t sb, int64_t st, int64_t sf, int B, int T, int F,
+                              float* partial, float* loss, float* drecon, hipStream_t s) {
+  const size_t n = (size_t)B * T * F;
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3(kMseBlocks), dim3(256), 0, s, recon, x, x_bf16, sb, st, sf, T, F, n, (float)(2.0 / (double)n),
+                     partial, drecon);
+  if (loss) hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, partial, kMseBlocks, 1.0 / (double)n, loss);
   return hipGetLastError();
 }
 hipError_t launch_cast_from_f32(int prec, const float* src, void* dst, size_t n, hipStream_t s) {

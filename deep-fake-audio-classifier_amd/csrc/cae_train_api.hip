@@ -118,7 +118,8 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
   if (!ctx) return DFA_E_NULL_PTR;
   CaeState& m = ctx->cae;
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_set_params has not been called");
-  if (!x || !recon || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, recon and workspace must be non-null");
+  if (!x || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x and workspace must be non-null");
+  if (!recon && !mse) return fail(ctx, DFA_E_NULL_PTR, "give recon, mse or both (the decoder's last kernel needs an output)");
   if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
   if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
   if (B < 1 || T < 16) return fail(ctx, DFA_E_BAD_SHAPE, "need B >= 1 and T >= 16 (got %d, %d)", B, T);
@@ -218,7 +219,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
   CaeState& m = ctx->cae;
   if (!m.train_packed || m.train_B != B || m.train_T != T)
     return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cae_backward must follow dfa_cae_forward_train on the same batch");
-  if (!x || !drecon || !grads || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, drecon, grads and workspace must be non-null");
+  if (!x || !grads || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, grads and workspace must be non-null");
   if (ngrads != 30) return fail(ctx, DFA_E_BAD_SHAPE, "the auto-encoder has 30 parameters, got %d gradient pointers", ngrads);
   for (int i = 0; i < 30; ++i)
     if (!grads[i]) return fail(ctx, DFA_E_NULL_PTR, "gradient pointer %d is null", i);
@@ -234,7 +235,10 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
   const int bf = (prec == DFA_PREC_BF16) ? 1 : 0;
   DropCfg nodrop{};
   // ---- decoder block 4
-  DFA_HIP_CHECK(ctx, launch_cae_dec4_bwd(prec, ws + pl.d[2], p[42], drecon, ws + pl.dd[2], partial, B, pl.Hd[2], pl.Wd[2], T, F, s));
+  // drecon == NULL: the loss is MSELoss(recon, x) (src/train_cae.py:67-68) and its gradient 2 (recon - x) / (B T F) is formed inside
+  // the kernel from the saved d3 and x -- neither recon nor drecon has to exist in memory
+  MseArgs ma{x, x_dtype == DFA_DTYPE_BF16 ? 1 : 0, stride_b, stride_t, stride_f, p[43]};
+  DFA_HIP_CHECK(ctx, launch_cae_dec4_bwd(prec, ws + pl.d[2], p[42], drecon, ws + pl.dd[2], partial, B, pl.Hd[2], pl.Wd[2], T, F, s, drecon ? nullptr : &ma));
   DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, cae_dec4_bwd_blocks(), 132, 1.0f, rec, s, nullptr));
   DFA_HIP_CHECK(ctx, hipMemcpyAsync(grads[28], rec, 128 * 4, hipMemcpyDeviceToDevice, s));
   DFA_HIP_CHECK(ctx, hipMemcpyAsync(grads[29], rec + 128, 4, hipMemcpyDeviceToDevice, s));
@@ -316,6 +320,21 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, rec, grads[0], grads[1]);
   }
   DFA_HIP_CHECK(ctx, hipGetLastError());
+  return DFA_OK;
+}
+
+int dfa_mse_fwd_bwd(dfa_ctx* ctx, const float* recon, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                    int64_t stride_t, int64_t stride_f, float* loss, float* drecon) {
+  TraceRange trace_("dfa_mse_fwd_bwd");
+  if (!ctx) return DFA_E_NULL_PTR;
+  if (!recon || !x) return fail(ctx, DFA_E_NULL_PTR, "recon and x must be non-null");
+  if (!loss && !drecon) return fail(ctx, DFA_E_NULL_PTR, "give loss, drecon or both");
+  if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
+  if (B < 1 || T < 1 || F < 1) return fail(ctx, DFA_E_BAD_SHAPE, "need B, T, F >= 1 (got %d, %d, %d)", B, T, F);
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->mse_partial) DFA_HIP_CHECK(ctx, hipMalloc((void**)&ctx->mse_partial, kMseBlocks * sizeof(float)));
+  DFA_HIP_CHECK(ctx, launch_mse_fwd_bwd(recon, x, x_dtype == DFA_DTYPE_BF16 ? 1 : 0, stride_b, stride_t, stride_f, B, T, F, ctx->mse_partial,
+                                        loss, drecon, ctx->stream));
   return DFA_OK;
 }
 

@@ -121,6 +121,10 @@ struct ConvArgs {
   // conv_split.hip PLAIN_BF16 (data gradient of block 2): thresh != 0 zeroes the elements the forward's dropout layer dropped
   // (same Philox draw, element index = output index) -- the keep mask of the pooled a1 applied where da1 is produced
   DropCfg drop;
+  // held-clock probe (conv3_m16.hip eval form; context option "clock_probe"): when non-null, lane 0 of the first 1024 workgroups
+  // (blockIdx.y = z = 0) writes {delta s_memtime (shader cycles), delta s_memrealtime (100 MHz ticks)} around its main loop to
+  // clock_stamps[2 * blockIdx.x ..]; never read by any kernel.  Null (the default): two scalar compares per workgroup.
+  long long* clock_stamps;
 };
 
 // chunk swizzle as a function of the pixel slot (column) only

@@ -100,6 +100,9 @@ struct dfa_ctx {
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
+  int clock_probe = 0;         // 1 = the bf16 block-3 kernel stamps its main loop (s_memtime / s_memrealtime) into clock_buf: dfa_ctx_clock_read
+  long long* clock_buf = nullptr;   // device, 1024 x {cycles, 100 MHz ticks}
+  float* mse_partial = nullptr;     // device, kMseBlocks floats: block sums of dfa_mse_fwd_bwd (allocated on first use)
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
   dfa::Cnn1dState cnn1d;
@@ -255,8 +258,19 @@ hipError_t launch_pixel_unshuffle(int prec, const void* dz, void* zp, int B, int
 hipError_t launch_convt_w_to_q(const float* w, float* wq, int cin, int cout, hipStream_t s);
 hipError_t launch_convt_q_to_w(const float* dwq, float* dw, int cin, int cout, hipStream_t s);
 int cae_dec4_bwd_blocks();
+// MSE form of the decoder-block-4 backward (drecon == nullptr): the upstream gradient 2 (recon - x) / (B T F) is formed in the kernel
+struct MseArgs {
+  const void* x;
+  int x_bf16;
+  int64_t sb, st, sf;
+  const float* b4_dev;
+};
 hipError_t launch_cae_dec4_bwd(int prec, const void* d3, const float* w4, const float* drecon, void* dd3, float* partial,
-                               int B, int H3, int W3, int T, int F, hipStream_t s);
+                               int B, int H3, int W3, int T, int F, hipStream_t s, const MseArgs* mse_args = nullptr);
+// loss = mean((recon - x)^2), drecon = 2 (recon - x) / n  (src/train_cae.py:67-68,203); partial: >= kMseBlocks floats of scratch
+constexpr int kMseBlocks = 1024;
+hipError_t launch_mse_fwd_bwd(const float* recon, const void* x, int x_bf16, int64_t sb, int64_t st, int64_t sf, int B, int T, int F,
+                              float* partial, float* loss, float* drecon, hipStream_t s);
 hipError_t launch_cast_from_f32(int prec, const float* src, void* dst, size_t n, hipStream_t s);
 hipError_t launch_reduce_wgrad_window(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
                                       int ci_off, int co_off, float* dw, hipStream_t s);

@@ -105,10 +105,17 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   TraceRange trace_("dfa_cnn2d_forward_train");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn2dState& m = ctx->cnn2d;
+  // The augmentation armed by dfa_cnn2d_set_train_augment is one-shot and belongs to THIS call: it is taken (and the arm cleared)
+  // before any check can return, so a failed forward never leaves it armed for an unrelated later batch.
+  const AugCfg armed = m.aug_armed;
+  m.aug_armed = AugCfg{};
+  m.train_aug = AugCfg{};
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn2d_set_params has not been called");
   if (!x || !logits || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, logits and workspace must be non-null");
   if (x_dtype != DFA_DTYPE_F32 && x_dtype != DFA_DTYPE_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "x dtype %d not supported", x_dtype);
   if (precision != DFA_PREC_F32 && precision != DFA_PREC_BF16) return fail(ctx, DFA_E_BAD_DTYPE, "unknown precision %d", precision);
+  if (armed.on && (armed.T != T || armed.F != F))
+    return fail(ctx, DFA_E_BAD_SHAPE, "the armed augmentation was drawn for [T=%d, F=%d], the batch is [T=%d, F=%d]", armed.T, armed.F, T, F);
   if (B < 1 || T < 4) return fail(ctx, DFA_E_BAD_SHAPE, "need B >= 1 and T >= 4 (got %d, %d)", B, T);
   if (F != m.in_features) return fail(ctx, DFA_E_BAD_SHAPE, "feature dim %d does not match in_features=%d", F, m.in_features);
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(ctx, DFA_E_BAD_SHAPE, "dropout p must be in [0, 1)");
@@ -168,12 +175,7 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   // ---- block 1
   StatPtrs s1 = stat_ptrs(ws, pl, 0);
   // augmentation armed by dfa_cnn2d_set_train_augment: one-shot, folded into the three kernels that read x
-  m.train_aug = m.aug_armed;
-  m.aug_armed = AugCfg{};
-  if (m.train_aug.on) {
-    if (m.train_aug.T != T || m.train_aug.F != F)
-      return fail(ctx, DFA_E_BAD_SHAPE, "the armed augmentation was drawn for [T=%d, F=%d], the batch is [T=%d, F=%d]", m.train_aug.T, m.train_aug.F, T, F);
-  }
+  m.train_aug = armed;
   const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
   m.train_c1_fused = ctx->conv1_bwd_fused ? 1 : 0;
   // matrix-core passes: bf16 mode on bf16 features without a folded augmentation (its noise makes x non-bf16), fused backward

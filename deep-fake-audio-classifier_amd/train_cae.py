@@ -26,13 +26,17 @@ def train_one_epoch(model, dataloader, criterion, optimizer, device="cuda"):
     """Mean reconstruction loss over the epoch (src/train_cae.py:58-82); the loss stays on the device until the end."""
     model.train()
     total, count = None, 0
+    native = hasattr(optimizer, "flat_g") and hasattr(optimizer, "step") and type(optimizer).__name__ == "CaeNativeTrainer"
     for x in dataloader:
         x = x.to(device, non_blocking=True)
-        recon, _ = model(x)
-        loss = criterion(recon, x)
-        optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
+        if native:                       # the whole step on the C ABI (criterion is MSELoss(recon, x) by construction)
+            loss = optimizer.step(x)
+        else:
+            recon, _ = model(x)
+            loss = criterion(recon, x)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
         term = loss.detach().double() * x.size(0)
         total = term if total is None else total + term
         count += x.size(0)
@@ -93,6 +97,9 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--normalizer-path", default=None)
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    p.add_argument("--trainer", default="native", choices=["native", "autograd"],
+                   help="native: the whole step on the C ABI (no reconstruction / loss-gradient tensors, fused AdamW); autograd: "
+                        "torch criterion + loss.backward() over the C-ABI autograd bridge")
     return p.parse_args(argv)
 
 
@@ -122,16 +129,18 @@ def main(argv=None):
     criterion = nn.MSELoss()
     sched_kw = dict(mode="min", factor=args.lr_scheduler_factor, patience=args.lr_scheduler_patience, threshold=1e-4,
                     min_lr=args.lr_scheduler_min_lr)
-    if world > 1:
-        # data parallel (src/train_cae.py:58-82 on every rank's shard): one flat 2,246,532-byte gradient all-reduce per
-        # step, fused AdamW, equal step counts on every rank
-        from .training.train_step import FlatTrainer
-        optimizer = FlatTrainer(model, lr=args.lr, weight_decay=args.weight_decay)
+    if world > 1 or args.trainer == "native":
+        # src/train_cae.py:58-82 on every rank's shard: one flat 2,246,532-byte gradient all-reduce per step (world > 1), fused
+        # AdamW, equal step counts on every rank
+        from .training.train_step import CaeNativeTrainer, FlatTrainer
+        Trainer = CaeNativeTrainer if args.trainer == "native" else FlatTrainer
+        optimizer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay)
         dfa_dist.broadcast_parameters_(optimizer.flat_p)
         scheduler = optimizer.plateau_scheduler(**sched_kw)
     else:
         optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, **sched_kw)
+    if world == 1:
         train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
         val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
     best, no_improve, last_epoch = None, 0, 0

@@ -44,6 +44,19 @@ def _bind_cnn2d(model, ctx):
     model._prepared = None   # eval-mode folded images are stale after any training step
 
 
+def _grad_sink(model):
+    """FlatTrainer's gradient views when every parameter's .grad still IS its view of the flat buffer: the C-ABI backward then
+    writes the gradients straight into the all-reduce payload (it writes, never accumulates) and autograd gets no tensors to
+    add -- no per-parameter allocation, no add kernels, no memset.  None = plain autograd semantics (fresh tensors returned)."""
+    sink = model.__dict__.get("_flat_grad_sink")
+    if sink is None:
+        return None
+    for p, g in zip(model.parameters(), sink):
+        if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+            return None
+    return sink
+
+
 def _next_dropout_offset(model, n_elems):
     off = getattr(model, "_drop_offset", 0)
     model._drop_offset = off + (n_elems + 3) // 4 + 1
@@ -133,48 +146,58 @@ def _bind_cnn1d(model, ctx):
     model._prepared = None
 
 
+def cnn1d_forward_train_raw(model, x):
+    """Run dfa_cnn1d_forward_train; returns (logits[B,1], ctx, workspace, generation)."""
+    if x.device.type != "cuda":
+        raise RuntimeError("dfa_amd.CNN1D runs on the GPU only: move the input with .to('cuda')")
+    if x.dtype != torch.float32:
+        raise ValueError(f"CNN1D takes float32 input, got {x.dtype}")
+    B, T, F = x.shape
+    ctx = _lib.Context.get(x.device)
+    with torch.cuda.device(ctx.index):
+        ctx.use_current_stream()
+        _bind_cnn1d(model, ctx)
+        nbytes = ctx.lib.dfa_cnn1d_train_workspace_bytes(ctx.handle, B, T, F)
+        ws = _train_ws(model, ctx, nbytes)
+        logits = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+        seed = getattr(model, "_drop_seed", None)
+        if seed is None:
+            seed = model._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        offset = _next_dropout_offset(model, B * 64 * T)
+        sb, st, sf = x.stride()
+        _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_forward_train(
+            ctx.handle, C.c_void_p(x.data_ptr()), _lib.DTYPE_F32, B, T, F, sb, st, sf, float(model.dropout), seed,
+            offset, 0.1, 1, C.c_void_p(logits.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel()))
+        torch._foreach_add_([model.conv[i].num_batches_tracked for i in model._BN_IDX], 1)
+    return logits, ctx, ws, ctx.next_train_gen("cnn1d")
+
+
+def cnn1d_backward_raw(model, x, dlogits, grad_tensors, ctx, ws, gen):
+    """dfa_cnn1d_backward with the 14 gradients WRITTEN into grad_tensors (e.g. views of one flat buffer)."""
+    ctx.check_train_gen("cnn1d", gen, model)
+    B, T, F = x.shape
+    with torch.cuda.device(ctx.index):
+        ctx.use_current_stream()
+        sb, st, sf = x.stride()
+        _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_backward(
+            ctx.handle, C.c_void_p(x.data_ptr()), _lib.DTYPE_F32, B, T, F, sb, st, sf, C.c_void_p(dlogits.data_ptr()),
+            _lib.ptr_array(grad_tensors), len(grad_tensors), C.c_void_p(ws.data_ptr()), ws.numel()))
+
+
 class Cnn1dTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(fctx, x, model, *params):
-        if x.device.type != "cuda":
-            raise RuntimeError("dfa_amd.CNN1D runs on the GPU only: move the input with .to('cuda')")
-        if x.dtype != torch.float32:
-            raise ValueError(f"CNN1D takes float32 input, got {x.dtype}")
-        B, T, F = x.shape
-        ctx = _lib.Context.get(x.device)
-        with torch.cuda.device(ctx.index):
-            ctx.use_current_stream()
-            _bind_cnn1d(model, ctx)
-            nbytes = ctx.lib.dfa_cnn1d_train_workspace_bytes(ctx.handle, B, T, F)
-            ws = _train_ws(model, ctx, nbytes)
-            logits = torch.empty((B, 1), dtype=torch.float32, device=x.device)
-            seed = getattr(model, "_drop_seed", None)
-            if seed is None:
-                seed = model._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-            offset = _next_dropout_offset(model, B * 64 * T)
-            sb, st, sf = x.stride()
-            _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_forward_train(
-                ctx.handle, C.c_void_p(x.data_ptr()), _lib.DTYPE_F32, B, T, F, sb, st, sf, float(model.dropout), seed,
-                offset, 0.1, 1, C.c_void_p(logits.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel()))
-            for i in model._BN_IDX:
-                model.conv[i].num_batches_tracked += 1
-        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, ctx.next_train_gen("cnn1d")
+        logits, ctx, ws, gen = cnn1d_forward_train_raw(model, x)
+        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, gen
         return logits
 
     @staticmethod
     def backward(fctx, dlogits):
-        model, x, ctx, ws = fctx.model, fctx.x, fctx.ctx, fctx.ws
-        ctx.check_train_gen("cnn1d", fctx.gen, model)
-        grads = [torch.empty_like(p) for p in model.parameters()]
-        B, T, F = x.shape
-        d = dlogits.contiguous().float()
-        with torch.cuda.device(ctx.index):
-            ctx.use_current_stream()
-            sb, st, sf = x.stride()
-            _lib.check(ctx.handle, ctx.lib.dfa_cnn1d_backward(
-                ctx.handle, C.c_void_p(x.data_ptr()), _lib.DTYPE_F32, B, T, F, sb, st, sf, C.c_void_p(d.data_ptr()),
-                _lib.ptr_array(grads), len(grads), C.c_void_p(ws.data_ptr()), ws.numel()))
-        return (None, None, *grads)
+        model = fctx.model
+        sink = _grad_sink(model)
+        grads = sink if sink is not None else [torch.empty_like(p) for p in model.parameters()]
+        cnn1d_backward_raw(model, fctx.x, dlogits.contiguous().float(), grads, fctx.ctx, fctx.ws, fctx.gen)
+        return (None, None, *([None] * len(grads) if sink is not None else grads))
 
 
 def cnn1d_train_forward(model, x):
@@ -195,54 +218,69 @@ def _bind_cae(model, ctx):
     model._prepared = None
 
 
+def cae_forward_train_raw(model, x, want_recon=True, want_latent=True, want_mse=False):
+    """Run dfa_cae_forward_train; returns (recon | None, latent | None, mse[B] | None, ctx, workspace, generation)."""
+    if x.device.type != "cuda":
+        raise RuntimeError("dfa_amd.ConvAutoencoder runs on the GPU only: move the input with .to('cuda')")
+    B, T, F = x.shape
+    ctx = _lib.Context.get(x.device)
+    with torch.cuda.device(ctx.index):
+        ctx.use_current_stream()
+        _bind_cae(model, ctx)
+        prec = _lib.PRECISIONS[model.precision]
+        nbytes = ctx.lib.dfa_cae_train_workspace_bytes(ctx.handle, B, T, F, prec)
+        if nbytes == 0:
+            raise ValueError(f"bad auto-encoder training shape (B={B}, T={T}, F={F}): need T >= 16 and F = 16k+4")
+        ws = _train_ws(model, ctx, nbytes)
+        recon = torch.empty((B, T, F), dtype=torch.float32, device=x.device) if want_recon else None
+        latent = torch.empty((B, 8 * model.base_channels, T // 16, F // 16), dtype=torch.float32, device=x.device) \
+            if want_latent else None
+        mse = torch.empty(B, dtype=torch.float32, device=x.device) if want_mse else None
+        sb, st, sf = x.stride()
+
+        def ptr(t):
+            return C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(ctx.handle, ctx.lib.dfa_cae_forward_train(
+            ctx.handle, C.c_void_p(x.data_ptr()), _lib.x_dtype_code(x), B, T, F, sb, st, sf, prec, 0.1, 1,
+            ptr(recon), ptr(latent), ptr(mse), C.c_void_p(ws.data_ptr()), ws.numel()))
+        bns = [model.encoder[bi].num_batches_tracked for _, bi in model._ENC]
+        bns += [model.decoder[bi].num_batches_tracked for _, bi in model._DEC if bi is not None]
+        torch._foreach_add_(bns, 1)
+    return recon, latent, mse, ctx, ws, ctx.next_train_gen("cae")
+
+
+def cae_backward_raw(model, x, drecon, grad_tensors, ctx, ws, gen):
+    """dfa_cae_backward with the 30 gradients WRITTEN into grad_tensors.  drecon = None: the loss is MSELoss(recon, x)
+    (src/train_cae.py:67-68) and its gradient is formed inside the decoder's last backward kernel."""
+    ctx.check_train_gen("cae", gen, model)
+    B, T, F = x.shape
+    with torch.cuda.device(ctx.index):
+        ctx.use_current_stream()
+        sb, st, sf = x.stride()
+        _lib.check(ctx.handle, ctx.lib.dfa_cae_backward(
+            ctx.handle, C.c_void_p(x.data_ptr()), _lib.x_dtype_code(x), B, T, F, sb, st, sf,
+            C.c_void_p(drecon.data_ptr()) if drecon is not None else None, _lib.ptr_array(grad_tensors), len(grad_tensors),
+            C.c_void_p(ws.data_ptr()), ws.numel()))
+
+
 class CaeTrainFunction(torch.autograd.Function):
     """(reconstruction, latent) = ConvAutoencoder(x) in train mode; the gradient flows through the reconstruction
     (src/train_cae.py:67-71 uses MSELoss(recon, x)); the latent map is returned for inspection only."""
 
     @staticmethod
     def forward(fctx, x, model, *params):
-        if x.device.type != "cuda":
-            raise RuntimeError("dfa_amd.ConvAutoencoder runs on the GPU only: move the input with .to('cuda')")
-        B, T, F = x.shape
-        ctx = _lib.Context.get(x.device)
-        with torch.cuda.device(ctx.index):
-            ctx.use_current_stream()
-            _bind_cae(model, ctx)
-            prec = _lib.PRECISIONS[model.precision]
-            nbytes = ctx.lib.dfa_cae_train_workspace_bytes(ctx.handle, B, T, F, prec)
-            if nbytes == 0:
-                raise ValueError(f"bad auto-encoder training shape (B={B}, T={T}, F={F}): need T >= 16 and F = 16k+4")
-            ws = _train_ws(model, ctx, nbytes)
-            recon = torch.empty((B, T, F), dtype=torch.float32, device=x.device)
-            latent = torch.empty((B, 8 * model.base_channels, T // 16, F // 16), dtype=torch.float32, device=x.device)
-            sb, st, sf = x.stride()
-            _lib.check(ctx.handle, ctx.lib.dfa_cae_forward_train(
-                ctx.handle, C.c_void_p(x.data_ptr()), _lib.x_dtype_code(x), B, T, F, sb, st, sf, prec, 0.1, 1,
-                C.c_void_p(recon.data_ptr()), C.c_void_p(latent.data_ptr()), None, C.c_void_p(ws.data_ptr()),
-                ws.numel()))
-            for _, bi in model._ENC:
-                model.encoder[bi].num_batches_tracked += 1
-            for _, bi in model._DEC:
-                if bi is not None:
-                    model.decoder[bi].num_batches_tracked += 1
-        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, ctx.next_train_gen("cae")
+        recon, latent, _, ctx, ws, gen = cae_forward_train_raw(model, x)
+        fctx.model, fctx.x, fctx.ctx, fctx.ws, fctx.gen = model, x, ctx, ws, gen
         fctx.mark_non_differentiable(latent)
         return recon, latent
 
     @staticmethod
     def backward(fctx, drecon, _dlatent):
-        model, x, ctx, ws = fctx.model, fctx.x, fctx.ctx, fctx.ws
-        ctx.check_train_gen("cae", fctx.gen, model)
-        grads = [torch.empty_like(p) for p in model.parameters()]
-        B, T, F = x.shape
-        d = drecon.contiguous().float()
-        with torch.cuda.device(ctx.index):
-            ctx.use_current_stream()
-            sb, st, sf = x.stride()
-            _lib.check(ctx.handle, ctx.lib.dfa_cae_backward(
-                ctx.handle, C.c_void_p(x.data_ptr()), _lib.x_dtype_code(x), B, T, F, sb, st, sf,
-                C.c_void_p(d.data_ptr()), _lib.ptr_array(grads), len(grads), C.c_void_p(ws.data_ptr()), ws.numel()))
-        return (None, None, *grads)
+        model = fctx.model
+        sink = _grad_sink(model)
+        grads = sink if sink is not None else [torch.empty_like(p) for p in model.parameters()]
+        cae_backward_raw(model, fctx.x, drecon.contiguous().float(), grads, fctx.ctx, fctx.ws, fctx.gen)
+        return (None, None, *([None] * len(grads) if sink is not None else grads))
 
 
 def cae_train_forward(model, x):
@@ -325,6 +363,8 @@ class _FlatAdamW:
             off += k
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if self._sched_opt is not None:       # the plateau scheduler's stand-in must resume from the restored lr too
+            self._sched_opt.param_groups[0]["lr"] = float(self.lr)
 
     def plateau_scheduler(self, **kw):
         """torch's ReduceLROnPlateau driving THIS trainer's lr (src/train.py:332-341,520-525): the scheduler owns a
@@ -349,9 +389,10 @@ class FlatTrainer(_FlatAdamW):
         super().__init__(model, **kw)
         for p, g in zip(model.parameters(), self.grad_views):
             p.grad = g
+        model.__dict__["_flat_grad_sink"] = self.grad_views     # CNN1D / auto-encoder bridges write into the views directly
 
     def zero_grad(self, set_to_none: bool = False):
-        self.flat_g.zero_()
+        """Re-attach the views; no memset: the dfa_*_backward calls WRITE every gradient (one backward per step on this path)."""
         for p, g in zip(self.model.parameters(), self.grad_views):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g
@@ -361,8 +402,9 @@ class FlatTrainer(_FlatAdamW):
 
 
 class NativeTrainer(_FlatAdamW):
-    """Whole CNN2D training step on the C ABI: forward_train -> BCE(smoothed) -> backward -> all-reduce -> fused AdamW,
-    with no autograd graph."""
+    """Whole classifier training step on the C ABI: forward_train -> BCE(smoothed) -> backward (gradients written straight
+    into the views of the flat buffer) -> all-reduce -> fused AdamW, with no autograd graph (src/train.py:71-76).
+    CNN2D and CNN1D (chosen by the model's class)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, label_smoothing=0.0,
                  process_group=None):
@@ -372,12 +414,16 @@ class NativeTrainer(_FlatAdamW):
         self.label_smoothing = label_smoothing
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
         self.dlogits = None
+        self.kind = "cnn1d" if type(model).__name__ == "CNN1D" else "cnn2d"
 
     def step(self, x, y):
         """One optimisation step on batch (x[B,T,F], y[B]); returns the (device) loss scalar of this rank's batch."""
         model = self.model
         model.train()
-        logits, ctx, ws = cnn2d_forward_train_raw(model, x)
+        if self.kind == "cnn1d":
+            logits, ctx, ws, gen = cnn1d_forward_train_raw(model, x)
+        else:
+            logits, ctx, ws = cnn2d_forward_train_raw(model, x)
         B = x.shape[0]
         if self.dlogits is None or self.dlogits.numel() != B:
             self.dlogits = torch.empty(B, dtype=torch.float32, device=x.device)
@@ -386,6 +432,32 @@ class NativeTrainer(_FlatAdamW):
             _lib.check(ctx.handle, ctx.lib.dfa_bce_smooth_fwd_bwd(
                 ctx.handle, C.c_void_p(logits.data_ptr()), C.c_void_p(y.data_ptr()), float(self.label_smoothing), B,
                 C.c_void_p(self.loss_buf.data_ptr()), C.c_void_p(self.dlogits.data_ptr())))
-        cnn2d_backward_raw(model, x, self.dlogits, self.grad_views, ctx, ws)
+        if self.kind == "cnn1d":
+            cnn1d_backward_raw(model, x, self.dlogits, self.grad_views, ctx, ws, gen)
+        else:
+            cnn2d_backward_raw(model, x, self.dlogits, self.grad_views, ctx, ws)
         self._exchange_and_update()
         return self.loss_buf
+
+
+class CaeNativeTrainer(_FlatAdamW):
+    """Whole auto-encoder training step on the C ABI (src/train_cae.py:58-82: recon = model(x); MSELoss(recon, x); backward;
+    AdamW): forward_train writes only the per-sample MSE, the backward forms 2 (recon - x) / N inside its first kernel
+    (dfa_cae_backward with drecon = NULL) and writes the 30 gradients straight into the flat buffer, then ONE 2,246,532-byte
+    all-reduce and the fused AdamW.  No reconstruction, no loss gradient, no autograd graph and no torch elementwise kernel."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, process_group=None):
+        super().__init__(model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, process_group=process_group)
+
+    def step(self, x):
+        """One optimisation step on the (z-scored) batch x[B,T,F]; returns the device scalar MSELoss(recon, x) of this rank."""
+        model = self.model
+        model.train()
+        _, _, mse, ctx, ws, gen = cae_forward_train_raw(model, x, want_recon=False, want_latent=False, want_mse=True)
+        cae_backward_raw(model, x, None, self.grad_views, ctx, ws, gen)
+        self._exchange_and_update()
+        return mse.mean()          # every sample has T*F elements: the mean of the per-sample MSEs is nn.MSELoss's mean
+
+
+def make_cae_trainer(model, **kw):
+    return CaeNativeTrainer(model, **kw)

@@ -88,6 +88,9 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   earlier 4-wave kernel (process-wide)
  *   "train_conv_variant" 2 (default) = pipelined two-wave bf16 training convolutions where they fit, 0 = their
  *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
+ *   "clock_probe"   1 = the dominant kernel of the bf16 eval forward (CNN2D block 3) brackets its main loop with s_memtime /
+ *                   s_memrealtime stamps (lane 0 of the first 1024 workgroups, into a buffer no kernel reads); dfa_ctx_clock_read
+ *                   returns the shader clock the chip held inside that kernel.  0 (default) = two scalar compares per workgroup
  *   "poison_lds"    (action, test hook) fills all 160 KB of LDS of every CU with the 16-bit pattern `value` (0xffff / 0x7fc0 =
  *                   NaN, 0x7f80 = +Inf) on the context's stream.  LDS is not cleared between workgroups; the stale-LDS tests
  *                   (tests/test_lds_poison_gpu.py) run every path after this and require bit-identical results
@@ -211,10 +214,14 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
 
 /* ConvAutoencoder training step (replaces, for src/train_cae.py:58-82, torch autograd over src/model_cae.py:32-125).
  * forward_train: x is the (already z-scored) input; BatchNorm uses batch statistics and updates the running statistics
- * in place when update_running_stats != 0; recon is required, latent / mse may be NULL.
- * backward: drecon = d(loss)/d(reconstruction), device float[B*T*F] (e.g. 2*(recon-x)/(B*T*F) for MSELoss); gradients
- * of the 30 parameters are written to grads[] in parameters() order: encoder.{0,1,4,5,8,9,12,13}.{weight,bias},
- * decoder.{0,1,3,4,6,7}.{weight,bias}, decoder.9.{weight,bias}. */
+ * in place when update_running_stats != 0; recon, latent and mse may each be NULL (at least one of recon / mse is required;
+ * mean_b mse[b] is MSELoss(recon, x) of src/train_cae.py:67-68, every sample having T*F elements).
+ * backward: drecon = d(loss)/d(reconstruction), device float[B*T*F] -- or NULL for the reference's own loss,
+ * MSELoss(recon, x) (src/train_cae.py:67-68,203): its gradient 2*(recon-x)/(B*T*F) is then formed INSIDE the decoder's last
+ * backward kernel from the saved activations and x, so neither the reconstruction nor its gradient has to exist in memory.
+ * Gradients of the 30 parameters are written to grads[] in parameters() order: encoder.{0,1,4,5,8,9,12,13}.{weight,bias},
+ * decoder.{0,1,3,4,6,7}.{weight,bias}, decoder.9.{weight,bias}; pointing grads[] into ONE flat buffer gives the single
+ * all-reduce payload of data-parallel training (2,246,532 bytes). */
 size_t dfa_cae_train_workspace_bytes(const dfa_ctx* ctx, int B, int T, int F, int precision);
 int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
                           int64_t stride_t, int64_t stride_f, int precision, float momentum,
@@ -223,6 +230,13 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
 int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b, int64_t stride_t,
                      int64_t stride_f, const float* drecon, float* const* grads, int ngrads, void* workspace,
                      size_t workspace_bytes);
+
+/* MSELoss(recon, x) forward + backward in one pass (replaces nn.MSELoss + its autograd node, src/train_cae.py:67-68,203):
+ * loss[0] = mean((recon - x)^2) over B*T*F elements (fixed-order two-stage reduction), drecon = 2*(recon - x)/(B*T*F).
+ * recon: device float[B*T*F] contiguous; x: as in dfa_cae_forward (dtype + element strides); loss / drecon: device, either may be
+ * NULL.  For callers that keep an explicit reconstruction; the native trainer uses dfa_cae_backward(drecon = NULL) instead. */
+int dfa_mse_fwd_bwd(dfa_ctx* ctx, const float* recon, const void* x, int x_dtype, int B, int T, int F, int64_t stride_b,
+                    int64_t stride_t, int64_t stride_f, float* loss, float* drecon);
 
 /* ---- shared ------------------------------------------------------------------------------------ */
 size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, int precision);
@@ -237,6 +251,12 @@ const char* dfa_dominant_kernel(int model, int precision);
 int dfa_ctx_timing_enable(dfa_ctx* ctx, int enable);
 int dfa_ctx_timing_reset(dfa_ctx* ctx);
 int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count);
+/* The shader clock (GHz) the chip held inside the LAST bf16 CNN2D block-3 launch made with option "clock_probe" = 1: per
+ * workgroup delta s_memtime / (delta s_memrealtime * 10 ns), median / min / max over the workgroups that stamped (at most
+ * 1024).  Synchronises on the context's stream.  The MFMA peak is quoted at 2.4 GHz; under MFMA load the chip holds less
+ * (MI355X_MICROARCH.md, DVFS give-back), so roofline fractions are reported both against the nominal peak and at this clock.
+ * ghz_min / ghz_max may be NULL. */
+int dfa_ctx_clock_read(dfa_ctx* ctx, double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups);
 
 #ifdef __cplusplus
 }

@@ -141,16 +141,20 @@ class _RoundGrad(torch.autograd.Function):
         return g.float().to(torch.bfloat16).to(g.dtype)
 
 
-def cnn2d_train_step_emulated(sd, x, y, label_smoothing=0.0, emulate="bf16"):
+def cnn2d_train_step_emulated(sd, x, y, label_smoothing=0.0, emulate="bf16", round_x=True, return_stats=False):
     """One CNN2D training forward/backward (dropout 0) restated with the ROUNDING POINTS of the product's bf16 training
     mode (src/train.py:71-76 over src/model.py:13-39 in train mode): a1, z2, a2, z3 and their gradients da1, dz2, da2, dz3
     are stored in bf16, the MFMA convolutions of blocks 2 and 3 (forward, data gradient, weight gradient) take bf16
     weights and bf16 activations, BatchNorm batch statistics come from the unrounded accumulators, block 1 / the time mean /
     the classifier / the loss are fp32.  Everything else is float64 with torch autograd.  emulate=None removes every
     rounding: the result must then equal the reference's autograd goldens (pins the restatement).
-    Returns (logits [B], loss, {parameter name: gradient}) with the names of the model's named_parameters()."""
+    round_x=False feeds x unrounded in bf16 mode too (a batch with folded jitter noise reaches block 1 in fp32).
+    Returns (logits [B], loss, {parameter name: gradient}) with the names of the model's named_parameters(); with
+    return_stats=True a fourth item {BatchNorm prefix: (batch mean, biased batch variance, element count)} from which the
+    running-statistics update of nn.BatchNorm2d follows (momentum m: (1-m)*old + m*mean, (1-m)*old + m*var*n/(n-1))."""
     f64 = torch.float64
     on = emulate == "bf16"
+    stats = {}
     if emulate not in (None, "bf16"):
         raise ValueError(emulate)
     P = {k: _t(sd, k).to(f64).clone().requires_grad_(True) for k in sd
@@ -163,14 +167,16 @@ def cnn2d_train_step_emulated(sd, x, y, label_smoothing=0.0, emulate="bf16"):
         za = rgrad(z)
         mean = za.mean(dim=(0, 2, 3), keepdim=True)
         var = za.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        stats[pfx] = (mean.detach().flatten().float(), var.detach().flatten().float(), za.numel() // za.shape[1])
         zs = rnd(za)
         return (zs - mean) / torch.sqrt(var + 1e-5) * P[pfx + ".weight"][None, :, None, None] + P[pfx + ".bias"][None, :, None, None]
 
-    xb = (x.to(torch.bfloat16) if on else x).to(f64).unsqueeze(1)
+    xb = (x.to(torch.bfloat16) if (on and round_x) else x).to(f64).unsqueeze(1)
     # block 1: fp32 VALU convolution from x, z1 is never stored (no rounding of z1 or dz1)
     z1 = F.conv2d(xb, P["conv.0.weight"], P["conv.0.bias"], padding=1)
     m1 = z1.mean(dim=(0, 2, 3), keepdim=True)
     v1 = z1.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    stats["conv.1"] = (m1.detach().flatten().float(), v1.detach().flatten().float(), z1.numel() // z1.shape[1])
     y1 = (z1 - m1) / torch.sqrt(v1 + 1e-5) * P["conv.1.weight"][None, :, None, None] + P["conv.1.bias"][None, :, None, None]
     a1 = store(F.avg_pool2d(F.relu(y1), (2, 1)))
     w2 = P["conv.5.weight"]
@@ -184,7 +190,53 @@ def cnn2d_train_step_emulated(sd, x, y, label_smoothing=0.0, emulate="bf16"):
     ys = y.to(f64) * (1.0 - label_smoothing) + 0.5 * label_smoothing if label_smoothing > 0 else y.to(f64)
     loss = F.binary_cross_entropy_with_logits(logits, ys)
     loss.backward()
-    return logits.detach().float(), float(loss), {k: v.grad.float() for k, v in P.items()}
+    out = (logits.detach().float(), float(loss), {k: v.grad.float() for k, v in P.items()})
+    return out + (stats,) if return_stats else out
+
+
+def cnn1d_train_step(sd, x, y, label_smoothing=0.0, return_stats=False):
+    """One CNN1D training forward/backward (dropout 0; src/train.py:71-76 over src/model_cnn1d.py:13-46 in train mode) in float64
+    with torch autograd -- the product's CNN1D path is fp32 end to end, so there are no rounding points to restate.  x is the
+    [B,T,F] view the harness feeds.  Returns (logits [B], loss, {parameter: gradient}[, {BatchNorm prefix: (mean, biased var, n)}])."""
+    f64 = torch.float64
+    P = {k: _t(sd, k).to(f64).clone().requires_grad_(True) for k in sd
+         if k.endswith(("weight", "bias")) and not k.endswith(("running_mean", "running_var"))}
+    stats = {}
+
+    def block(h, conv, bn):
+        z = F.conv1d(h, P[conv + ".weight"], P[conv + ".bias"], padding=1)
+        mean = z.mean(dim=(0, 2), keepdim=True)
+        var = z.var(dim=(0, 2), unbiased=False, keepdim=True)
+        stats[bn] = (mean.detach().flatten().float(), var.detach().flatten().float(), z.numel() // z.shape[1])
+        return F.relu((z - mean) / torch.sqrt(var + 1e-5) * P[bn + ".weight"][None, :, None] + P[bn + ".bias"][None, :, None])
+    h = block(x.to(f64).transpose(1, 2), "conv.0", "conv.1")
+    h = block(h, "conv.4", "conv.5")
+    h = block(h, "conv.8", "conv.9")
+    logits = F.linear(h.mean(dim=2), P["classifier.weight"], P["classifier.bias"]).squeeze(-1)
+    ys = y.to(f64) * (1.0 - label_smoothing) + 0.5 * label_smoothing if label_smoothing > 0 else y.to(f64)
+    loss = F.binary_cross_entropy_with_logits(logits, ys)
+    loss.backward()
+    out = (logits.detach().float(), float(loss), {k: v.grad.float() for k, v in P.items()})
+    return out + (stats,) if return_stats else out
+
+
+def state_after_adamw_step(sd, grads, stats, lr=1e-3, weight_decay=0.01, momentum=0.1):
+    """The state_dict one optimiser step later: torch.optim.AdamW(lr, weight_decay) on the given gradients (src/train.py:326-328,
+    74-76) plus the running-statistics update nn.BatchNorm performs in the train-mode forward (momentum 0.1, unbiased variance).
+    `stats` = {BatchNorm prefix: (batch mean, biased batch variance, element count)} as the *_train_step oracles return them."""
+    out = {k: _t(sd, k).clone() for k in sd}
+    params = [torch.nn.Parameter(out[k].float().clone()) for k in grads]
+    for p, k in zip(params, grads):
+        p.grad = grads[k].float().clone()
+    torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay).step()
+    for p, k in zip(params, grads):
+        out[k] = p.detach().clone()
+    for bn, (mean, var, n) in stats.items():
+        out[bn + ".running_mean"] = (1 - momentum) * out[bn + ".running_mean"].float() + momentum * mean
+        out[bn + ".running_var"] = (1 - momentum) * out[bn + ".running_var"].float() + momentum * var * (n / max(n - 1, 1))
+        if bn + ".num_batches_tracked" in out:
+            out[bn + ".num_batches_tracked"] = out[bn + ".num_batches_tracked"] + 1
+    return out
 
 
 def cae_train_step_emulated(sd, x, emulate="bf16"):
