@@ -443,7 +443,7 @@ def other_models_metric(torch, device, B, steps=20, warmup=5):
     torch.manual_seed(0)
     out = {}
     m1 = CNN1D(in_features=F).to(device).eval()
-    r = rate(lambda: m1(x), slots=(("conv1", 4), ("conv2", 5), ("conv3", 6), ("linear", 7)))
+    r = rate(lambda: m1(x), slots=(("cnn1d_fused_or_conv1", 4), ("conv2", 5), ("conv3", 6), ("linear", 7)))
     k_ms = sum(r["kernel_ms"].values()) if r.get("kernel_ms") else r["ms_per_step"]
     gbs = B * CNN1D_BYTES_PER_UTT / (k_ms * 1e-3) / 1e9
     traffic, src = pmc_step_traffic("cnn1d_fwd")

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("dfa_ctx_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("dfa_ctx_timing_reset", C.c_int, [C.c_void_p]),
     ("dfa_ctx_timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("dfa_ctx_debug_read", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]),
     ("dfa_ctx_clock_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int)]),
 ]

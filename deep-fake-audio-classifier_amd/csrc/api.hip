@@ -158,6 +158,7 @@ int dfa_ctx_destroy(dfa_ctx* ctx) {
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
   if (ctx->mse_partial) (void)hipFree(ctx->mse_partial);
+  if (ctx->aug_keep) (void)hipFree(ctx->aug_keep);
   for (auto& t : ctx->slots) {
     for (auto e : t.start) (void)hipEventDestroy(e);
     for (auto e : t.stop) (void)hipEventDestroy(e);
@@ -217,6 +218,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "fuse_conv1") == 0) { ctx->fuse_conv1 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "lds_pipe") == 0) { ctx->lds_pipe = value ? 1 : 0; return DFA_OK; }
@@ -272,6 +274,16 @@ int dfa_ctx_clock_read(dfa_ctx* ctx, double* ghz_median, double* ghz_min, double
   if (ghz_min) *ghz_min = g[0];
   if (ghz_max) *ghz_max = g[n - 1];
   *workgroups = n;
+  return DFA_OK;
+}
+
+int dfa_ctx_debug_read(dfa_ctx* ctx, long long* host_words, int n) {
+  if (!ctx || !host_words) return DFA_E_NULL_PTR;
+  if (n < 0 || n > 2048) return fail(ctx, DFA_E_BAD_SHAPE, "the probe buffer holds 2048 words (got %d)", n);
+  if (!ctx->clock_buf) return fail(ctx, DFA_E_NOT_PREPARED, "set the context option clock_probe = 1 first");
+  DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  DFA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  DFA_HIP_CHECK(ctx, hipMemcpy(host_words, ctx->clock_buf, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return DFA_OK;
 }
 
@@ -463,6 +475,8 @@ int dfa_cnn1d_prepare(dfa_ctx* ctx) {
   size_t off[3], boff[3], total = 0;
   for (int l = 0; l < 3; ++l) { off[l] = total; total = align_up(total + (size_t)cout[l] * cin[l] * 3 * 4, 256); }
   for (int l = 0; l < 3; ++l) { boff[l] = total; total = align_up(total + (size_t)cout[l] * 4, 256); }
+  size_t poff[3];
+  for (int l = 0; l < 3; ++l) { poff[l] = total; total = align_up(total + cnn1d_fused_pack_floats(cin[l], cout[l], l) * 4, 256); }
   if (m.packed) { DFA_HIP_CHECK(ctx, hipFree(m.packed)); m.packed = nullptr; }
   DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, total));
   for (int l = 0; l < 3; ++l) {
@@ -470,6 +484,8 @@ int dfa_cnn1d_prepare(dfa_ctx* ctx) {
     m.b[l] = (float*)((char*)m.packed + boff[l]);
     const float* const* q = m.p + 6 * l;
     DFA_HIP_CHECK(ctx, launch_fold_conv1d(q[0], q[1], q[2], q[3], q[4], q[5], m.w[l], m.b[l], cin[l], cout[l], ctx->stream));
+    m.wp[l] = (float*)((char*)m.packed + poff[l]);
+    DFA_HIP_CHECK(ctx, launch_pack_cnn1d_fused(m.w[l], m.wp[l], cin[l], cout[l], l, ctx->stream));
   }
   m.prepared = true;
   return DFA_OK;
@@ -491,6 +507,14 @@ int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   char* ws = (char*)workspace;
   float *h1 = (float*)(ws + pl.h1_off), *h2 = (float*)(ws + pl.h2_off), *pooled = (float*)(ws + pl.pooled_off);
   hipStream_t s = ctx->stream;
+  // (the fused kernel addresses an utterance's elements with 32-bit offsets)
+  const bool off32 = stride_t >= 0 && stride_f >= 0 && (int64_t)(F - 1) * stride_f + (int64_t)(T - 1) * stride_t < ((int64_t)1 << 31);
+  if (ctx->cnn1d_fused && cnn1d_fused_supports(T) && off32) {   // one kernel, one global write per utterance (timing slot 4)
+    ScopedSlot ts(ctx, 4);
+    DFA_HIP_CHECK(ctx, launch_cnn1d_fused((const float*)x, stride_b, stride_t, stride_f, m.wp[0], m.b[0], m.wp[1], m.b[1], m.wp[2], m.b[2],
+                                          m.p[18], m.p[19], logits, B, T, F, s, ctx->clock_probe ? ctx->clock_buf : nullptr));
+    return DFA_OK;
+  }
   { ScopedSlot ts(ctx, 4);
     DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, m.w[0], m.b[0], h1, B, F, 32, T, false, s)); }
   { ScopedSlot ts(ctx, 5);

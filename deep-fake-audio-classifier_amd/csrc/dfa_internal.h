@@ -64,6 +64,7 @@ struct Cnn1dState {
   int in_features = 0;
   void* packed = nullptr;
   float *w[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
+  float* wp[3] = {nullptr, nullptr, nullptr};   // MFMA A-fragment images of the folded weights (cnn1d_fused.hip)
   // train mode: data-gradient weight images of conv layers 2 and 3 (+ a zero bias), dropout state
   void* train_packed = nullptr;
   float *wt[2] = {nullptr, nullptr}, *zero_bias = nullptr;
@@ -100,8 +101,11 @@ struct dfa_ctx {
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
+  int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel (cnn1d_fused.hip) when T <= 384; 0 = the three-launch path
   int clock_probe = 0;         // 1 = the bf16 block-3 kernel stamps its main loop (s_memtime / s_memrealtime) into clock_buf: dfa_ctx_clock_read
   long long* clock_buf = nullptr;   // device, 1024 x {cycles, 100 MHz ticks}
+  float* aug_keep = nullptr;        // device copy of the armed augmentation's keep mask (dfa_cnn2d_set_train_augment copies keep_f)
+  int aug_keep_cap = 0, aug_keep_slot = 0;
   float* mse_partial = nullptr;     // device, kMseBlocks floats: block sums of dfa_mse_fwd_bwd (allocated on first use)
   int conv_dma = -1;           // conv input staging: 1 = global_load_lds (LDS-DMA), 0 = through registers, -1 = per-kernel default
   dfa::Cnn2dState cnn2d;
@@ -183,6 +187,14 @@ hipError_t launch_emb_reduce(const float* parts, int nparts, size_t stride, size
 // conv1d.hip
 hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
+// cnn1d_fused.hip: the whole CNN1D eval forward as one kernel (fp32 matrix cores, activations in LDS)
+int cnn1d_fused_ncp_pad(int cin, int layer);
+size_t cnn1d_fused_pack_floats(int cin, int cout, int layer);
+bool cnn1d_fused_supports(int T);
+hipError_t launch_pack_cnn1d_fused(const float* wf, float* wp, int cin, int cout, int layer, hipStream_t s);
+hipError_t launch_cnn1d_fused(const float* x, int64_t sb, int64_t st, int64_t sf, const float* wp1, const float* b1, const float* wp2,
+                              const float* b2, const float* wp3, const float* b3, const float* cw, const float* cb, float* logits, int B,
+                              int T, int F, hipStream_t s, long long* stamps = nullptr);
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
                          float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu = true);
 // train_cnn1d.hip

@@ -337,8 +337,25 @@ int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shif
       fmask_start + fmask_len > F)
     return fail(ctx, DFA_E_BAD_SHAPE, "mask span outside the batch");
   if (!(jitter_std >= 0.f)) return fail(ctx, DFA_E_BAD_SHAPE, "jitter std must be >= 0");
+  // The keep mask is COPIED (stream-ordered) into one of two context-owned buffers, alternating per call: the caller's tensor may
+  // be freed as soon as this returns (a temporary FusedAugment did exactly that in a test and the backward read recycled memory),
+  // and arming batch n+1 cannot disturb the backward of batch n.
+  const float* keep_dev = nullptr;
+  if (keep_f) {
+    DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->aug_keep_cap < F) {
+      if (ctx->aug_keep) { DFA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); DFA_HIP_CHECK(ctx, hipFree(ctx->aug_keep)); ctx->aug_keep = nullptr; }
+      const int cap = F < 1024 ? 1024 : F;
+      DFA_HIP_CHECK(ctx, hipMalloc((void**)&ctx->aug_keep, (size_t)2 * cap * sizeof(float)));
+      ctx->aug_keep_cap = cap;
+    }
+    ctx->aug_keep_slot ^= 1;
+    float* dst = ctx->aug_keep + (size_t)ctx->aug_keep_slot * ctx->aug_keep_cap;
+    DFA_HIP_CHECK(ctx, hipMemcpyAsync(dst, keep_f, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    keep_dev = dst;
+  }
   AugCfg a{};
-  a.on = 1; a.T = T; a.F = F; a.shift = ((shift % T) + T) % T; a.keep = keep_f;
+  a.on = 1; a.T = T; a.F = F; a.shift = ((shift % T) + T) % T; a.keep = keep_dev;
   a.tm_start = tmask_start; a.tm_len = tmask_len; a.fm_start = fmask_start; a.fm_len = fmask_len;
   a.std = jitter_std; a.seed = seed; a.offset = offset;
   m.aug_armed = a;

@@ -88,6 +88,8 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   earlier 4-wave kernel (process-wide)
  *   "train_conv_variant" 2 (default) = pipelined two-wave bf16 training convolutions where they fit, 0 = their
  *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
+ *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel (all three Conv1d layers on the fp32 matrix cores with the
+ *                   activations in LDS, the frame mean and the classifier in its epilogue) for T <= 384; 0 = the three-launch path
  *   "clock_probe"   1 = the dominant kernel of the bf16 eval forward (CNN2D block 3) brackets its main loop with s_memtime /
  *                   s_memrealtime stamps (lane 0 of the first 1024 workgroups, into a buffer no kernel reads); dfa_ctx_clock_read
  *                   returns the shader clock the chip held inside that kernel.  0 (default) = two scalar compares per workgroup
@@ -157,8 +159,9 @@ int dfa_augment_batch(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
  * augmentation to the batch and hands the result to the model): arms the parameters for the NEXT dfa_cnn2d_forward_train /
  * dfa_cnn2d_backward pair, whose three kernels that read x (statistics pass, block 1, block-1 backward) then read
  * keep_f[f] * mask(x[b][(t - shift) mod T][f]) + jitter_std * N(0,1) instead of x -- no augmented copy of the batch is
- * written or re-read.  One-shot: consumed by that forward; enable = 0 disarms.  keep_f (device float[F] or NULL) must stay
- * valid until the backward has run.  The element formula, noise stream included, is the one of dfa_augment_batch. */
+ * written or re-read.  One-shot: consumed by that forward (also by one that fails its argument checks); enable = 0 disarms.
+ * keep_f (device float[F] or NULL) is copied into a context-owned buffer on the stream: the caller's tensor may be released at
+ * once.  The element formula, noise stream included, is the one of dfa_augment_batch. */
 int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
                                 int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
                                 uint64_t offset);
@@ -244,7 +247,7 @@ size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, i
 const char* dfa_dominant_kernel(int model, int precision);
 /* ---- per-kernel timing (HIP events recorded on the context's stream around every launch) -------------
  * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear;
- * CNN1D: 4, 5, 6 = conv blocks, 7 = linear;  CAE: 8 = enc1, 9-11 = enc2-4 (MFMA), 12-14 = dec1-3 (MFMA), 15 = dec4+MSE.
+ * CNN1D: 4 = the fused forward (three-launch path: 4, 5, 6 = conv blocks, 7 = linear);  CAE: 8 = enc1, 9-11 = enc2-4 (MFMA), 12-14 = dec1-3 (MFMA), 15 = dec4+MSE.
  * enable: 0 = off, 1 = all slots, any other value = bit mask of slots (e.g. 1<<2 = block 3 only).
  * Enable, run forwards, then read (read synchronises on the recorded events; call it outside timed regions).
  * At most 256 launches per slot are recorded between resets. */
@@ -257,6 +260,10 @@ int dfa_ctx_timing_read(dfa_ctx* ctx, int slot, float* total_ms, int* count);
  * (MI355X_MICROARCH.md, DVFS give-back), so roofline fractions are reported both against the nominal peak and at this clock.
  * ghz_min / ghz_max may be NULL. */
 int dfa_ctx_clock_read(dfa_ctx* ctx, double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups);
+/* Raw copy of the first n (<= 2048) 64-bit words of the probe buffer the "clock_probe" kernels stamp (diagnostics: the fused CNN1D
+ * kernel writes, per workgroup b < 128, words 8b..8b+3 = s_memtime at start / after layer 1 / after layer 2 / at the end and
+ * 8b+5, 8b+6 = s_memrealtime at start / end).  Synchronises on the context's stream. */
+int dfa_ctx_debug_read(dfa_ctx* ctx, long long* host_words, int n);
 
 #ifdef __cplusplus
 }

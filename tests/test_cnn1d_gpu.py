@@ -31,9 +31,14 @@ def test_cnn1d_layers_match_golden(golden):
     sd, g = golden("cnn1d_eval")
     model = _model(sd)
     x = torch.from_numpy(g["t16.x_stored"]).to("cuda").transpose(1, 2)
-    model(x)
     from dfa_amd import _lib
-    ws = _lib.Context.get(x.device)._ws
+    ctx = _lib.Context.get(x.device)
+    ctx.set_option("cnn1d_fused", 0)          # the three-launch path keeps h1 / h2 in the workspace (the fused kernel keeps them in LDS)
+    try:
+        model(x)
+    finally:
+        ctx.set_option("cnn1d_fused", 1)
+    ws = ctx._ws
     T = 16
     n1 = 32 * T * 4
     off2 = (n1 + 255) // 256 * 256
@@ -64,3 +69,61 @@ def test_cnn1d_errors(golden):
         model(torch.zeros(2, 321, 180, device="cuda", dtype=torch.bfloat16))
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 321, 180))
+
+
+@pytest.mark.parametrize("B,T,F,layout", [(5, 321, 180, "bft_view"), (3, 321, 180, "btf"), (2, 1, 180, "bft_view"), (2, 2, 180, "btf"),
+                                          (4, 33, 180, "bft_view"), (2, 384, 180, "bft_view"), (2, 385, 180, "bft_view"),
+                                          (3, 97, 65, "btf"), (2, 40, 5, "bft_view"), (1, 64, 33, "bft_view")])
+def test_cnn1d_fused_kernel_matches_three_launch_path_and_oracle(B, T, F, layout):
+    """Round 3: the whole CNN1D forward as ONE kernel (csrc/cnn1d_fused.hip: fp32 matrix cores, activations in LDS, frame mean
+    and classifier in the epilogue) against the three-launch path it replaces and the numpy oracle, over frame counts that are
+    not multiples of the 32-frame tile, single frames, the largest T that fits LDS (384; 385 falls back), odd channel counts
+    (zero-padded channel pair) and both input layouts.  fp32 fma chains on both sides: 1e-4 (the reference bar), measured ~1e-6."""
+    from dfa_amd import _lib
+    from dfa_amd.model_cnn1d import CNN1D
+    torch.manual_seed(T + F)
+    m = CNN1D(in_features=F)
+    gen = torch.Generator().manual_seed(B * 1000 + T)
+    with torch.no_grad():
+        for i in (1, 5, 9):
+            m.conv[i].running_mean.copy_(0.2 * torch.randn(m.conv[i].running_mean.shape, generator=gen))
+            m.conv[i].running_var.copy_(0.5 + torch.rand(m.conv[i].running_var.shape, generator=gen))
+            m.conv[i].weight.copy_(0.5 + torch.rand(m.conv[i].weight.shape, generator=gen))
+            m.conv[i].bias.copy_(0.1 * torch.randn(m.conv[i].bias.shape, generator=gen))
+        m.classifier.weight.mul_(20.0)
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    m = m.to("cuda").eval()
+    stored = torch.randn(B, F, T, generator=gen) * 3.2 - 0.07 if layout == "bft_view" else torch.randn(B, T, F, generator=gen) * 3.2 - 0.07
+    x = stored.to("cuda").transpose(1, 2) if layout == "bft_view" else stored.to("cuda")
+    ctx = _lib.Context.get(x.device)
+    fused = m(x).cpu().numpy()
+    ctx.set_option("cnn1d_fused", 0)
+    try:
+        three = m(x).cpu().numpy()
+    finally:
+        ctx.set_option("cnn1d_fused", 1)
+    want = O.cnn1d_forward(sd, (stored.numpy().swapaxes(1, 2) if layout == "bft_view" else stored.numpy()))
+    np.testing.assert_allclose(fused, want, atol=TOL_F32, rtol=0)
+    np.testing.assert_allclose(fused, three, atol=2e-5, rtol=0)
+    assert np.isfinite(fused).all()
+
+
+def test_cnn1d_fused_is_one_launch_and_batch_independent(golden):
+    """One timing slot (4) fires per forward on the fused path, none of the per-layer slots; an utterance's logit does not depend
+    on its neighbours in the batch (bit for bit: one workgroup per utterance)."""
+    from dfa_amd import _lib
+    sd, _ = golden("cnn1d_eval")
+    model = _model(sd)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(7, 180, 321, generator=g) * 3.2).to("cuda").transpose(1, 2)
+    ctx = _lib.Context.get(x.device)
+    ctx.timing_reset()
+    ctx.timing(True)
+    full = model(x)
+    ctx.timing(False)
+    torch.cuda.synchronize()
+    counts = [ctx.timing_read(s)[1] for s in (4, 5, 6, 7)]
+    ctx.timing_reset()
+    assert counts == [1, 0, 0, 0], counts
+    for i in (0, 3, 6):
+        assert torch.equal(model(x[i:i + 1]), full[i:i + 1])
