@@ -455,7 +455,7 @@ def other_models_metric(torch, device, B, steps=20, warmup=5):
     cae = ConvAutoencoder(precision="bf16").to(device).eval()
     x16 = x.to(torch.bfloat16)
     r = rate(lambda: cae.score(x16, mean, std),
-             slots=(("enc1", 8), ("enc2", 9), ("enc3", 10), ("enc4", 11), ("dec1", 12), ("dec2", 13), ("dec3", 14), ("dec4_mse", 15)))
+             slots=(("enc1", 8), ("enc2", 9), ("enc3", 10), ("enc4", 11), ("decoder_fused_mse", 12), ("dec2", 13), ("dec3", 14), ("dec4_mse", 15)))
     tf = B * CAE_FLOPS_PER_UTT / (r["ms_per_step"] * 1e-3) / 1e12
     traffic, src = pmc_step_traffic("cae_score")
     r["roofline"] = {"bound": "mfma", "scope": "whole score (encoder + decoder + MSE), algorithmic FLOPs / wall time",

@@ -218,6 +218,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "cae_dec_fused") == 0) { ctx->cae_dec_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "fuse_conv1") == 0) { ctx->fuse_conv1 = value ? 1 : 0; return DFA_OK; }
@@ -553,6 +554,8 @@ int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
   for (int l = 0; l < 3; ++l) { db[l] = off; off = align_up(off + dcout[l] * 4, 256); }
   for (int l = 0; l < 3; ++l) { ew[l] = off; off = align_up(off + (size_t)ecout[l] * ecin[l] * 9 * 4, 256); }
   for (int l = 0; l < 3; ++l) { dw[l] = off; off = align_up(off + (size_t)dcout[l] * dcin[l] * 4 * 4, 256); }
+  const size_t cst_off = off;
+  off = align_up(off + 16 * sizeof(float), 256);
   if (!m.packed) DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, off));
   char* base = (char*)m.packed;
   m.w1 = (float*)base;
@@ -582,6 +585,9 @@ int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
     const float* const* q = p + 24 + 6 * l;
     DFA_HIP_CHECK(ctx, launch_fold_pack_convt2x2(q[0], q[1], q[2], q[3], q[4], q[5], dcin[l], dcout[l], precision, m.dec[l].wpack, m.dec[l].bias, s));
   }
+  m.opad_cst = (float*)(base + cst_off);
+  if (precision == DFA_PREC_BF16)   // the constants the fused decoder uses for the columns grown from block 2's output_padding column
+    DFA_HIP_CHECK(ctx, launch_cae_opad_consts(m.dec[1].bias, m.dec[2].wpack, m.dec[2].bias, p[42], p[43], m.opad_cst, s));
   m.prepared_prec = precision;
   return DFA_OK;
 }
@@ -621,6 +627,17 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
     DFA_HIP_CHECK(ctx, err);
   }
   if (latent) DFA_HIP_CHECK(ctx, launch_cae_latent_export(e[3], prec, latent, B, pl.H[4] * pl.W[4], 256, s));
+  if (prec == DFA_PREC_BF16 && ctx->cae_dec_fused) {   // decoder + squared error in one kernel: d1, d2, d3 never leave the CU (slot 12)
+    if (recon || mse) {
+      ScopedSlot ts(ctx, 12);
+      float* partial = (float*)(ws + pl.part_off);
+      DFA_HIP_CHECK(ctx, launch_cae_dec_fused(e[3], m.dec[0].wpack, m.dec[0].bias, m.dec[1].wpack, m.dec[1].bias, m.dec[2].wpack, m.dec[2].bias,
+                                              m.p[42], m.p[43], m.opad_cst, x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, recon, partial,
+                                              B, pl.H[4], pl.W[4], T, F, s, ctx->clock_probe ? ctx->clock_buf : nullptr));
+      if (mse) DFA_HIP_CHECK(ctx, launch_cae_mse_finalize(partial, cae_dec_fused_tiles(pl.H[4], pl.W[4]), 1.0f / ((float)T * (float)F), mse, B, s));
+    }
+    return DFA_OK;
+  }
   const int dcin[3] = {256, 128, 64}, dcout[3] = {128, 64, 32};
   for (int l = 0; l < 3; ++l) {
     ScopedSlot ts(ctx, 12 + l);

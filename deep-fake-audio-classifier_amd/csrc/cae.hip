@@ -236,6 +236,11 @@ hipError_t launch_cae_dec4_mse(const void* d3, int prec, const float* w4, const 
   return e;
 }
 
+hipError_t launch_cae_mse_finalize(const float* partial, int nblk, float inv_n, float* mse, int B, hipStream_t s) {
+  hipLaunchKernelGGL(cae_mse_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, s, partial, nblk, inv_n, mse, B);
+  return hipGetLastError();
+}
+
 hipError_t launch_cae_latent_export(const void* lat, int prec, float* out, int B, int HW, int C, hipStream_t s) {
   const size_t n = (size_t)B * C * HW;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);

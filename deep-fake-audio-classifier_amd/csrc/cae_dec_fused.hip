@@ -1,0 +1,286 @@
+// cae_dec_fused.hip -- the auto-encoder's whole decoder + reconstruction error as ONE kernel (bf16 storage mode):
+//   ConvT 256->128 + BN + ReLU -> ConvT 128->64 (output_padding (0,1)) + BN + ReLU -> ConvT 64->32 + BN + ReLU -> ConvT 32->1
+//   -> zero-pad T -> per-sample mean((recon - x)^2)        (src/model_cae.py:57-80,107-125; src/evaluation_cae.py:52-53).
+//
+// ConvTranspose2d(kernel 2, stride 2) never overlaps: a latent pixel owns its 2x2 -> 4x4 -> 8x8 -> 16x16 patch, so the three
+// intermediates (d1, d2, d3: 3.2 MB per utterance written and re-read by the four-launch path, 0.55 ms of its 1.25 ms) need never
+// leave the CU.  A workgroup takes 32 consecutive latent pixels of one utterance (16 KB, contiguous: channels-last) and runs the
+// chain with the activations in LDS:
+//   phase A  d1[128 px][128] = relu(W1 . lat)     M = 512 (q, co) x N = 32  x K = 256    256 MFMAs
+//   phase B  d2[512 px][64]  = relu(W2 . d1)      M = 256         x N = 128 x K = 128    256 MFMAs
+//   phase C  d3 = relu(W3 . d2) in REGISTERS      M = 128         x N = 512 x K = 64     256 MFMAs, then the 32 -> 1 layer as 64 FMAs
+//            per lane on its 16 channels + one half-wave exchange, the z-scored x read through the caller's strides, and the
+//            squared error -- no d3, no reconstruction in memory (recon is written only when the caller asks for it).
+// v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (the packed images of convt2x2_mfma.h serve unchanged: the register
+// image of a B-operand column block is that of an A-operand row block) and pixels as columns: a lane then holds 4 consecutive
+// channels x 4 groups of one pixel, so outputs leave as 8-byte LDS stores (the four-launch kernels store single bf16 elements).
+// Pixel order is the quadtree order (child = 4 * parent + q): only phase C maps a pixel back to (t, f).  Rounding points are those
+// of the four-launch path (d1, d2, d3 rounded to bf16, fp32 accumulation), so the emulated-oracle tests apply unchanged.
+// The output_padding column of block 2 is a per-channel constant, and so is everything grown from it: reconstruction columns
+// 16 W4 .. 16 W4 + 3 are a 4 x 4 pattern of constants (row mod 4, column) computed once at prepare time (cae_opad_consts_kernel);
+// the last workgroup of an utterance adds their error and that of the zero rows t >= 16 H4.
+#include "dfa_internal.h"
+#include "convt2x2_mfma.h"
+
+namespace dfa {
+
+struct CaeDecFusedArgs {
+  const bf16_t* lat;               // [B][H4*W4][256]
+  const uint4 *wp1, *wp2, *wp3;    // [4*COUT/32][CIN/16][64] x 16 bytes (launch_fold_pack_convt2x2, bf16)
+  const float *b1, *b2, *b3;       // folded biases [128], [64], [32]
+  const float *w4, *b4;            // ConvTranspose2d(32 -> 1) weight [32][4], bias [1] (raw, fp32)
+  const float* cst;                // [16] reconstruction constants of the output_padding columns: cst[(t & 3) * 4 + (f - 16 W4)]
+  const void* x;
+  int x_bf16;
+  int64_t sb, st, sf;
+  const float *mu, *sigma;         // fused FeatureNormalizer z-score, or null
+  float* recon;                    // [B][T][F] or null
+  float* partial;                  // [B][ntile] squared-error sums
+  int H4, W4, T, F, ntile;
+  long long* stamps;               // diagnostic (context option "clock_probe"): s_memtime at the phase boundaries, workgroups (tile, b < 18)
+};
+
+namespace cdf {
+constexpr int NP = 32;                       // latent pixels per workgroup
+constexpr int LAT_B = NP * 512, D1_B = 4 * NP * 256, D2_B = 16 * NP * 128;
+constexpr int W4_OFF = LAT_B + D1_B + D2_B;  // [32] float4
+constexpr int RED_OFF = W4_OFF + 512;        // [8] float
+constexpr int LDS_BYTES = RED_OFF + 64;
+}  // namespace cdf
+
+__device__ __forceinline__ float cdf_ldx(const CaeDecFusedArgs& a, int b, int t, int f) {
+  const int64_t off = (int64_t)b * a.sb + (int64_t)t * a.st + (int64_t)f * a.sf;
+  float v = a.x_bf16 ? bf16_to_float(((const bf16_t*)a.x)[off]) : ((const float*)a.x)[off];
+  if (a.mu) v = (v - a.mu[f]) / a.sigma[f];
+  return v;
+}
+
+__global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a) {
+  using namespace cdf;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const latS = smem;
+  char* const d1S = smem + LAT_B;
+  char* const d2S = smem + LAT_B + D1_B;
+  float4* const w4S = (float4*)(smem + W4_OFF);
+  float* const red = (float*)(smem + RED_OFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int npx = a.H4 * a.W4, g0 = tile * NP;
+  const float rlim = relu_limit();
+  const int sid = b * a.ntile + tile;
+  const bool stamp = a.stamps != nullptr && tid == 0 && sid < 128;
+  if (stamp) { a.stamps[8 * sid] = __builtin_amdgcn_s_memtime(); a.stamps[8 * sid + 6] = __builtin_amdgcn_s_memrealtime(); }
+
+  // ---- stage the latent tile (32 pixels x 512 B, contiguous) with the chunk swizzle of the fragment reads; W4 -> LDS
+  {
+    const char* src = (const char*)(a.lat + ((size_t)b * npx + g0) * 256);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g = tid + 512 * it, p = g >> 5, c = g & 31;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (g0 + p < npx) v = *(const uint4*)(src + (size_t)g * 16);
+      *(uint4*)(latS + p * 512 + ((c ^ (p & 15)) << 4)) = v;
+    }
+    if (tid < 32) w4S[tid] = make_float4(a.w4[4 * tid], a.w4[4 * tid + 1], a.w4[4 * tid + 2], a.w4[4 * tid + 3]);
+  }
+  __syncthreads();
+  if (stamp) a.stamps[8 * sid + 1] = __builtin_amdgcn_s_memtime();
+
+  // bias + ReLU + bf16 of one accumulator, 4 consecutive channels per 8-byte store at pixel P (row pitch PB, swizzle SW)
+  auto store_tile = [&](const f32x16_t& acc, const float* bias, int co_base, char* dst, int P, int PB, int sw) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co_base + 8 * g + 4 * h;
+      const float4 bv = *(const float4*)(bias + co);
+      const unsigned lo = pack_bf16x2(relu1(acc[4 * g] + bv.x, rlim), relu1(acc[4 * g + 1] + bv.y, rlim));
+      const unsigned hi = pack_bf16x2(relu1(acc[4 * g + 2] + bv.z, rlim), relu1(acc[4 * g + 3] + bv.w, rlim));
+      *(uint2*)(dst + P * PB + ((((co >> 3)) ^ sw) << 4) + 8 * h) = make_uint2(lo, hi);
+    }
+  };
+
+  // ---- phase A: d1 = relu(W1 . lat): wave owns m-tiles 2 wave, 2 wave + 1 (n = q1 * 128 + co)
+  {
+    uint4 wa[16], wn[16];
+    const uint4* wp = a.wp1 + lane;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) wa[kg] = wp[(size_t)((2 * wave) * 16 + kg) * 64];
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) wn[kg] = wp[(size_t)((2 * wave + 1) * 16 + kg) * 64];
+    const char* xb = latS + col * 512;
+    const int sw = col & 15;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int mt = 2 * wave + mi;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < 16; ++kg) {
+        const uint4 xv = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
+        acc = Mma<bf16_t>::run(mi == 0 ? wa[kg] : wn[kg], xv, acc);
+      }
+      const int P1 = 4 * col + (mt >> 2);
+      store_tile(acc, a.b1, 32 * (mt & 3), d1S, P1, 256, P1 & 15);
+    }
+  }
+  __syncthreads();
+  if (stamp) a.stamps[8 * sid + 2] = __builtin_amdgcn_s_memtime();
+
+  // ---- phase B: d2 = relu(W2 . d1): wave owns m-tile `wave` (n = q2 * 64 + co) for the four 32-pixel column tiles
+  {
+    uint4 wa[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) wa[kg] = a.wp2[(size_t)(wave * 8 + kg) * 64 + lane];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int P1 = 32 * nt + col;
+      const char* xb = d1S + P1 * 256;
+      const int sw = P1 & 15;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const uint4 xv = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
+        acc = Mma<bf16_t>::run(wa[kg], xv, acc);
+      }
+      const int P2 = 4 * P1 + (wave >> 1);
+      store_tile(acc, a.b2, 32 * (wave & 1), d2S, P2, 128, (P2 >> 1) & 7);
+    }
+  }
+  __syncthreads();
+  if (stamp) a.stamps[8 * sid + 3] = __builtin_amdgcn_s_memtime();
+
+  // ---- phase C: d3 = relu(W3 . d2) in registers (m-tile = q3, all 32 channels of a pixel over the two lane halves), the
+  //      32 -> 1 transposed convolution, and the squared error against x
+  float err = 0.f;
+  {
+    uint4 wa[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) wa[mt][kg] = a.wp3[(size_t)(mt * 4 + kg) * 64 + lane];
+    float b3v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b3v[r] = a.b3[(r & 3) + 8 * (r >> 2) + 4 * h];
+    const float b4 = a.b4[0];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int P2 = 32 * (2 * wave + ni) + col;
+      const char* xb = d2S + P2 * 128;
+      const int sw = (P2 >> 1) & 7;
+      uint4 xv[4];
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) xv[kg] = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
+      const int p = P2 >> 4, q1 = (P2 >> 2) & 3, q2 = P2 & 3;
+      const int g = g0 + p;
+      const bool valid = g < npx;
+      const int i4 = g / a.W4, j4 = g - i4 * a.W4;
+      const int tq = 16 * i4 + 8 * (q1 >> 1) + 4 * (q2 >> 1), fq = 16 * j4 + 8 * (q1 & 1) + 4 * (q2 & 1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) acc = Mma<bf16_t>::run(wa[mt][kg], xv[kg], acc);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = bf16_to_float(float_to_bf16(relu1(acc[r] + b3v[r], rlim)));   // d3 is a bf16 tensor in this mode
+          const float4 w = w4S[(r & 3) + 8 * (r >> 2) + 4 * h];
+          s0 = fmaf(v, w.x, s0); s1 = fmaf(v, w.y, s1); s2 = fmaf(v, w.z, s2); s3 = fmaf(v, w.w, s3);
+        }
+        s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); s3 += __shfl_xor(s3, 32, 64);
+        // half h finishes output row a4 = h of the pixel's 2 x 2 patch
+        const float r0 = (h ? s2 : s0) + b4, r1 = (h ? s3 : s1) + b4;
+        const int t = tq + 2 * (mt >> 1) + h, f = fq + 2 * (mt & 1);
+        if (valid) {
+          const float d0 = r0 - cdf_ldx(a, b, t, f), d1 = r1 - cdf_ldx(a, b, t, f + 1);
+          err = fmaf(d0, d0, err);
+          err = fmaf(d1, d1, err);
+          if (a.recon) *reinterpret_cast<float2*>(a.recon + ((size_t)b * a.T + t) * a.F + f) = make_float2(r0, r1);
+        }
+      }
+    }
+  }
+  // ---- the output_padding columns (constants) and the zero rows t >= 16 H4: the utterance's last workgroup
+  if (tile == a.ntile - 1) {
+    const int HR = 16 * a.H4, f0 = 16 * a.W4, nstrip = HR * 4, ntail = (a.T - HR) * a.F;
+    for (int i = tid; i < nstrip + ntail; i += 512) {
+      int t, f;
+      float r;
+      if (i < nstrip) { t = i >> 2; f = f0 + (i & 3); r = a.cst[(t & 3) * 4 + (i & 3)]; }
+      else { const int k = i - nstrip; t = HR + k / a.F; f = k - (t - HR) * a.F; r = 0.f; }
+      const float d = r - cdf_ldx(a, b, t, f);
+      err = fmaf(d, d, err);
+      if (a.recon) a.recon[((size_t)b * a.T + t) * a.F + f] = r;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) err += __shfl_down(err, off, 64);
+  if (lane == 0) red[wave] = err;
+  __syncthreads();
+  if (stamp) { a.stamps[8 * sid + 4] = __builtin_amdgcn_s_memtime(); a.stamps[8 * sid + 7] = __builtin_amdgcn_s_memrealtime(); }
+  if (tid == 0)
+    a.partial[(size_t)b * a.ntile + tile] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+// Reconstruction values of the columns grown from block 2's output_padding column (a per-channel constant):
+//   c2[ci] = bf16(relu(b2[ci]));  c3[q3][co] = bf16(relu(b3[co] + sum_ci W3[ci][q3, co] c2[ci]))  (W3 = the bf16 MFMA image);
+//   cst[(2 a3 + a4) * 4 + 2 c3 + c4] = b4 + sum_co c3[(a3, c3)][co] * W4[co][(a4, c4)].
+__global__ __launch_bounds__(128) void cae_opad_consts_kernel(const float* __restrict__ b2, const uint4* __restrict__ wp3,
+                                                              const float* __restrict__ b3, const float* __restrict__ w4,
+                                                              const float* __restrict__ b4, float* __restrict__ cst) {
+  __shared__ float c2[64], c3[4][32];
+  const int tid = threadIdx.x;
+  if (tid < 64) c2[tid] = bf16_to_float(float_to_bf16(fmaxf(b2[tid], 0.f)));
+  __syncthreads();
+  {
+    const int q3 = tid >> 5, co = tid & 31;
+    float s = b3[co];
+    for (int ci = 0; ci < 64; ++ci) {
+      const int kg = ci >> 4, hh = (ci >> 3) & 1, j = ci & 7;
+      const unsigned short* frag = (const unsigned short*)(wp3 + (size_t)(q3 * 4 + kg) * 64 + co + 32 * hh);
+      bf16_t w;
+      w.v = frag[j];
+      s = fmaf(bf16_to_float(w), c2[ci], s);
+    }
+    c3[q3][co] = bf16_to_float(float_to_bf16(fmaxf(s, 0.f)));
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int q3 = tid >> 2, q4 = tid & 3;
+    float s = b4[0];
+    for (int co = 0; co < 32; ++co) s = fmaf(c3[q3][co], w4[co * 4 + q4], s);
+    const int trow = 2 * (q3 >> 1) + (q4 >> 1), fcol = 2 * (q3 & 1) + (q4 & 1);
+    cst[trow * 4 + fcol] = s;
+  }
+}
+
+hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float* b3, const float* w4, const float* b4, float* cst,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(cae_opad_consts_kernel, dim3(1), dim3(128), 0, s, b2, wp3, b3, w4, b4, cst);
+  return hipGetLastError();
+}
+
+int cae_dec_fused_tiles(int H4, int W4) { return (H4 * W4 + cdf::NP - 1) / cdf::NP; }
+
+hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* b1, const uint4* wp2, const float* b2, const uint4* wp3,
+                                const float* b3, const float* w4, const float* b4, const float* cst, const void* x, int x_dtype,
+                                int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon, float* partial,
+                                int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps) {
+  CaeDecFusedArgs a{};
+  a.stamps = stamps;
+  a.lat = (const bf16_t*)lat; a.wp1 = wp1; a.wp2 = wp2; a.wp3 = wp3; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.w4 = w4; a.b4 = b4; a.cst = cst;
+  a.x = x; a.x_bf16 = x_dtype == DFA_DTYPE_BF16 ? 1 : 0; a.sb = sb; a.st = st; a.sf = sf; a.mu = mu; a.sigma = sigma;
+  a.recon = recon; a.partial = partial; a.H4 = H4; a.W4 = W4; a.T = T; a.F = F; a.ntile = cae_dec_fused_tiles(H4, W4);
+  hipError_t e = hipFuncSetAttribute((const void*)cae_dec_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cdf::LDS_BYTES);
+  if (e != hipSuccess) return e;     // (per device: set on every launch, it is cheap)
+  hipLaunchKernelGGL(cae_dec_fused_kernel, dim3(a.ntile, B), dim3(512), cdf::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

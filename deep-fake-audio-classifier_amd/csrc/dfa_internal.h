@@ -80,6 +80,7 @@ struct CaeState {
   float *w1 = nullptr, *b1 = nullptr;
   PackedConv enc[3];   // encoder blocks 2-4
   PackedConv dec[3];   // decoder blocks 1-3 (ConvTranspose2d images)
+  float* opad_cst = nullptr;   // [16] reconstruction constants of the output_padding columns (cae_dec_fused.hip)
   // train mode (cae_train_api.hip): raw forward images, data-gradient images, raw ConvTranspose2d images
   void* train_packed = nullptr;
   float *tw1 = nullptr, *tb1 = nullptr;
@@ -101,6 +102,7 @@ struct dfa_ctx {
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
+  int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel (cnn1d_fused.hip) when T <= 384; 0 = the three-launch path
   int clock_probe = 0;         // 1 = the bf16 block-3 kernel stamps its main loop (s_memtime / s_memrealtime) into clock_buf: dfa_ctx_clock_read
   long long* clock_buf = nullptr;   // device, 1024 x {cycles, 100 MHz ticks}
@@ -187,6 +189,15 @@ hipError_t launch_emb_reduce(const float* parts, int nparts, size_t stride, size
 // conv1d.hip
 hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
+// cae_dec_fused.hip: the auto-encoder's decoder + per-sample squared error as one kernel (bf16 mode)
+int cae_dec_fused_tiles(int H4, int W4);
+hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float* b3, const float* w4, const float* b4, float* cst,
+                                  hipStream_t s);
+hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* b1, const uint4* wp2, const float* b2, const uint4* wp3,
+                                const float* b3, const float* w4, const float* b4, const float* cst, const void* x, int x_dtype,
+                                int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon, float* partial,
+                                int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps = nullptr);
+hipError_t launch_cae_mse_finalize(const float* partial, int nblk, float inv_n, float* mse, int B, hipStream_t s);
 // cnn1d_fused.hip: the whole CNN1D eval forward as one kernel (fp32 matrix cores, activations in LDS)
 int cnn1d_fused_ncp_pad(int cin, int layer);
 size_t cnn1d_fused_pack_floats(int cin, int cout, int layer);

@@ -88,6 +88,8 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   earlier 4-wave kernel (process-wide)
  *   "train_conv_variant" 2 (default) = pipelined two-wave bf16 training convolutions where they fit, 0 = their
  *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
+ *   "cae_dec_fused" 1 (default) = auto-encoder eval forward in bf16 mode: the four decoder blocks, the zero time padding and the
+ *                   per-sample squared error run as ONE kernel with the intermediates in LDS / registers; 0 = four launches
  *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel (all three Conv1d layers on the fp32 matrix cores with the
  *                   activations in LDS, the frame mean and the classifier in its epilogue) for T <= 384; 0 = the three-launch path
  *   "clock_probe"   1 = the dominant kernel of the bf16 eval forward (CNN2D block 3) brackets its main loop with s_memtime /
@@ -247,7 +249,7 @@ size_t dfa_workspace_bytes(const dfa_ctx* ctx, int model, int B, int T, int F, i
 const char* dfa_dominant_kernel(int model, int precision);
 /* ---- per-kernel timing (HIP events recorded on the context's stream around every launch) -------------
  * slots for CNN2D: 0 = conv1, 1 = block 2 (MFMA), 2 = block 3 (MFMA, the dominant kernel), 3 = linear;
- * CNN1D: 4 = the fused forward (three-launch path: 4, 5, 6 = conv blocks, 7 = linear);  CAE: 8 = enc1, 9-11 = enc2-4 (MFMA), 12-14 = dec1-3 (MFMA), 15 = dec4+MSE.
+ * CNN1D: 4 = the fused forward (three-launch path: 4, 5, 6 = conv blocks, 7 = linear);  CAE: 8 = enc1, 9-11 = enc2-4 (MFMA), 12 = fused decoder + MSE (bf16 mode; four-launch path: 12-14 = dec1-3, 15 = dec4+MSE).
  * enable: 0 = off, 1 = all slots, any other value = bit mask of slots (e.g. 1<<2 = block 3 only).
  * Enable, run forwards, then read (read synchronises on the recorded events; call it outside timed regions).
  * At most 256 launches per slot are recorded between resets. */

@@ -132,3 +132,63 @@ def test_pipelined_fp32_accin_kernel_depth4_matches_twin(golden):
     finally:
         ctx.set_option("train_conv_variant", 2)
     assert torch.equal(l0, l1) and torch.equal(r0, r1)
+
+
+@pytest.mark.parametrize("B,T,F,xdt,view", [(3, 321, 180, torch.float32, False), (2, 321, 180, torch.bfloat16, True), (5, 70, 180, torch.float32, True),
+                                             (2, 64, 36, torch.float32, False), (1, 16, 20, torch.bfloat16, False), (4, 130, 52, torch.float32, True)])
+def test_cae_fused_decoder_matches_four_launch_path(golden, B, T, F, xdt, view):
+    """Round 3: the decoder + per-sample squared error as ONE kernel (csrc/cae_dec_fused.hip; bf16 mode) against the four-launch
+    path it replaces (context option cae_dec_fused = 0), same rounding points: reconstruction (incl. the output_padding columns'
+    constants and the zero rows t >= 16 (T // 16)), score with and without the fused z-score, fp32 / bf16 / strided inputs, latent
+    grids that do not fill the last 32-pixel tile (20 x 11 = 220, 4 x 2 = 8, 1 x 1) and the emulated oracle."""
+    from dfa_amd import _lib
+    from dfa_amd.model_cae import ConvAutoencoder
+    from oracle import torch_ref as R
+    sd, _ = golden("cae_eval")
+    model = _model(sd, precision="bf16")
+    gen = torch.Generator().manual_seed(B * 100 + T + F)
+    stored = torch.randn(B, F, T, generator=gen) if view else torch.randn(B, T, F, generator=gen)
+    x = stored.to("cuda", xdt)
+    x = x.transpose(1, 2) if view else x
+    mean, std = 0.1 * torch.randn(F, generator=gen), 0.5 + torch.rand(F, generator=gen)
+    ctx = _lib.Context.get(x.device)
+    if F != 180:      # the golden weights are for any F (fully convolutional); only the shapes change
+        assert F % 16 == 4
+    got_r, got_l = model(x)
+    got_s = model.score(x)
+    got_sz = model.score(x, mean, std)
+    ctx.set_option("cae_dec_fused", 0)
+    try:
+        ref_r, ref_l = model(x)
+        ref_s = model.score(x)
+        ref_sz = model.score(x, mean, std)
+    finally:
+        ctx.set_option("cae_dec_fused", 1)
+    assert torch.equal(got_l, ref_l)
+    scale = max(1.0, float(ref_r.abs().max()))
+    assert float((got_r - ref_r).abs().max()) <= 2e-5 * scale, float((got_r - ref_r).abs().max())
+    if T % 16:
+        assert torch.all(got_r[:, 16 * (T // 16):, :] == 0)
+    np.testing.assert_allclose(got_s.cpu().numpy(), ref_s.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(got_sz.cpu().numpy(), ref_sz.cpu().numpy(), rtol=2e-5)
+    # score == mean((recon - x)^2) of the kernel's own reconstruction
+    np.testing.assert_allclose(got_s.cpu().numpy(), ((got_r - x.float()) ** 2).mean(dim=(1, 2)).cpu().numpy(), rtol=2e-5)
+    want_r, _ = R.cae_forward_emulated(sd, x.float().cpu(), "bf16")
+    assert float((got_r.cpu() - want_r).abs().max()) / max(1.0, float(want_r.abs().max())) < 4e-3
+
+
+def test_cae_fused_decoder_is_one_launch(golden):
+    from dfa_amd import _lib
+    sd, _ = golden("cae_eval")
+    model = _model(sd, precision="bf16")
+    x = torch.randn(3, 321, 180, device="cuda")
+    ctx = _lib.Context.get(x.device)
+    model.score(x)
+    ctx.timing_reset()
+    ctx.timing(True)
+    model.score(x)
+    ctx.timing(False)
+    torch.cuda.synchronize()
+    counts = [ctx.timing_read(s)[1] for s in range(8, 16)]
+    ctx.timing_reset()
+    assert counts == [1, 1, 1, 1, 1, 0, 0, 0], counts
