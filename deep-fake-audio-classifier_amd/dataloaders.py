@@ -94,3 +94,91 @@ class FlatBatcher:
             if l is not None:
                 l.record_stream(torch.cuda.current_stream(self.device))
             yield f, l
+
+
+class IndexedFlatBatcher:
+    """Batches of ARBITRARY rows of a flat [N,180,321] source -- the data-parallel TRAINING loader (the
+    reference's shuffled DataLoader, src/dataloaders.py:55-59 / src/train.py:279-285, on every rank's share).
+
+    `features` is any row-indexable tensor: the zero-copy view of a memory-mapped flat file (ingest.FlatFeatures.tensor(): a
+    rank then reads ONLY the rows it trains on -- 1/world of the set per epoch, never the whole pickle) or an in-memory stack.
+    `indices` are this rank's sample indices for the epoch in consumption order (dataloaders.train_shard_indices).  Each batch is
+    gathered on the host into a (pinned) staging buffer and copied to the device on a side stream, one batch ahead of the
+    consumer.  `rows_fetched` / `bytes_fetched` count what this rank pulled from the source."""
+
+    def __init__(self, features: torch.Tensor, labels: torch.Tensor | None, indices: torch.Tensor, batch_size: int,
+                 device="cuda", dtype: torch.dtype | None = None, pin: bool = True):
+        self.features, self.labels = features, labels
+        self.indices = indices.to(torch.int64).reshape(-1)
+        self.batch_size, self.device, self.dtype = int(batch_size), torch.device(device), dtype
+        self.pin = bool(pin) and self.device.type == "cuda"
+        self.rows_fetched = 0
+        self.bytes_fetched = 0
+        self._row_bytes = int(features[0].numel() * features.element_size()) if len(features) else 0
+
+    def __len__(self):
+        return -(-self.indices.numel() // self.batch_size)
+
+    def _gather(self, lo, hi):
+        idx = self.indices[lo:hi]
+        rows = self.features[idx]                       # fancy index: copies exactly these rows out of the (memory-mapped) source
+        self.rows_fetched += int(idx.numel())
+        self.bytes_fetched += int(idx.numel()) * self._row_bytes
+        lab = None if self.labels is None else self.labels[idx]
+        if self.pin:
+            rows = rows.pin_memory()
+        return rows, lab
+
+    def _put(self, lo, hi, stream):
+        rows, lab = self._gather(lo, hi)
+        with torch.cuda.stream(stream):
+            f = rows.to(self.device, non_blocking=True)
+            if self.dtype is not None:
+                f = f.to(self.dtype)
+            l = None if lab is None else lab.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return f, l, ev, rows                           # `rows` keeps the pinned staging buffer alive until the copy is consumed
+
+    def __iter__(self):
+        n = self.indices.numel()
+        starts = list(range(0, n, self.batch_size))
+        if self.device.type != "cuda":
+            for lo in starts:
+                rows, lab = self._gather(lo, min(lo + self.batch_size, n))
+                yield (rows if self.dtype is None else rows.to(self.dtype)), lab
+            return
+        copy_stream = torch.cuda.Stream(self.device)
+        nxt = self._put(starts[0], min(starts[0] + self.batch_size, n), copy_stream) if starts else None
+        for i, lo in enumerate(starts):
+            f, l, ev, _keep = nxt
+            if i + 1 < len(starts):
+                nlo = starts[i + 1]
+                nxt = self._put(nlo, min(nlo + self.batch_size, n), copy_stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            f.record_stream(torch.cuda.current_stream(self.device))
+            if l is not None:
+                l.record_stream(torch.cuda.current_stream(self.device))
+            yield f, l
+
+
+def open_flat(features_path: str, labels_path: str | None, cache_dir: str, rank: int = 0, world: int = 1, tag: str = "set"):
+    """(features tensor [N,180,321] zero-copy over a memory-mapped flat file, labels [N] float32 or None, uttids) for the
+    data-parallel drivers.  `features_path` is either a flat prefix made by `python -m dfa_amd.ingest` (<prefix>.npy +
+    <prefix>.json: nothing is un-pickled by anyone) or the reference's features.pkl: then RANK 0 ALONE converts it once into
+    `cache_dir/<tag>_flat.*` (ingest.convert), the other ranks wait at a barrier and map the result -- instead of every rank
+    un-pickling, stacking and pinning the whole set."""
+    import os
+    from . import ingest
+    import torch.distributed as dist
+    if os.path.exists(features_path + ".npy") and os.path.exists(features_path + ".json"):
+        prefix = features_path
+    else:
+        prefix = os.path.join(cache_dir, f"{tag}_flat")
+        if rank == 0:
+            os.makedirs(cache_dir, exist_ok=True)
+            ingest.convert(features_path, prefix, labels_path, dtype="fp32")
+        if world > 1 and dist.is_available() and dist.is_initialized():
+            dist.barrier()
+    ff = ingest.FlatFeatures(prefix)
+    return ff.tensor(), ff.labels, ff.uttids

@@ -49,15 +49,29 @@ def allreduce_flat_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
-def gather_scores(local_scores, group=None) -> np.ndarray:
-    """All ranks get the concatenation (rank order) of every rank's score vector; shards may have different lengths."""
+def gather_scores(local_scores, group=None, device=None) -> np.ndarray:
+    """All ranks get the concatenation (rank order) of every rank's score vector.  Shards may have different lengths: one tiny
+    all-gather of the lengths, then ONE tensor all-gather of the scores padded to the longest shard (float64; over RCCL the
+    tensors live on `device`) -- no pickling of python objects on the per-epoch path."""
     import torch.distributed as dist
-    local = np.asarray(local_scores, dtype=np.float64)
+    local = np.asarray(local_scores, dtype=np.float64).reshape(-1)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, local, group=group)
-    return np.concatenate(parts)
+    world = dist.get_world_size(group)
+    dev = device if (dist.get_backend(group) == "nccl" and device is not None) else torch.device("cpu")
+    if dist.get_backend(group) == "nccl" and device is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    lens = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([local.size], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(lens, mine, group=group)
+    lens = lens.cpu().tolist()
+    per = max(max(lens), 1)
+    buf = torch.zeros(per, dtype=torch.float64, device=dev)
+    buf[:local.size] = torch.from_numpy(local).to(dev)
+    out = torch.empty(world * per, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.cpu().numpy().reshape(world, per)
+    return np.concatenate([out[r, :lens[r]] for r in range(world)])
 
 
 def broadcast_parameters_(flat_params: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:

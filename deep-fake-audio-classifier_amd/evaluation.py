@@ -113,7 +113,7 @@ def evaluate_sharded(model, features: torch.Tensor, labels: torch.Tensor, criter
             x = feats.transpose(1, 2) if swap_tf else feats
             chunks.append(model(x).squeeze(-1).detach())
     local = torch.cat(chunks).double().cpu().numpy() if chunks else np.zeros(0)
-    logits = dfa_dist.gather_scores(local)
+    logits = dfa_dist.gather_scores(local, device=torch.device(device) if str(device).startswith("cuda") else None)
     y = labels.double().cpu().numpy()
     if len(logits) != len(y):
         raise ValueError(f"gathered {len(logits)} scores for {len(y)} labels")

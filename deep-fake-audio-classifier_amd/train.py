@@ -21,7 +21,7 @@ from torch import nn
 
 from . import distributed as dfa_dist
 from .augmentation import FusedAugment, channel_drop, compose, gaussian_jitter, spec_augment, time_shift
-from .dataloaders import FlatBatcher, make_loader, train_shard_indices
+from .dataloaders import FlatBatcher, IndexedFlatBatcher, make_loader, open_flat, train_shard_indices
 from .dataset import AudioDeepfakeDataset
 from .evaluation import evaluate, evaluate_sharded
 from .model import CNN2D
@@ -197,8 +197,11 @@ def main(argv=None):
         trainer = NativeTrainer(model, lr=args.lr, weight_decay=weight_decay, label_smoothing=args.label_smoothing)
         dfa_dist.broadcast_parameters_(trainer.flat_p)
         dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
-        feats, labels = AudioDeepfakeDataset(args.train_features, args.train_labels).stacked(pin=True)
-        dev_feats, dev_labels = AudioDeepfakeDataset(args.dev_features, args.dev_labels).stacked(pin=True)
+        # Flat, memory-mapped sources: a rank reads only the rows it consumes (1 / world of the training set per epoch, its
+        # contiguous share of the dev set); a features.pkl is converted ONCE, by rank 0 (dataloaders.open_flat)
+        cache = os.path.join(out_dir, "flat_cache")
+        feats, labels, _ = open_flat(args.train_features, args.train_labels, cache, rank, world, "train")
+        dev_feats, dev_labels, _ = open_flat(args.dev_features, args.dev_labels, cache, rank, world, "dev")
         optimizer = trainer
     else:
         optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=weight_decay)
@@ -221,7 +224,7 @@ def main(argv=None):
             # local batch sizes on all ranks (dataloaders.train_shard_indices)
             perm = torch.randperm(feats.shape[0], generator=torch.Generator().manual_seed(args.seed + epoch))
             idx = train_shard_indices(perm, args.batch_size, rank, world)
-            batcher = FlatBatcher(feats[idx], labels[idx], args.batch_size, device=device)
+            batcher = IndexedFlatBatcher(feats, labels, idx, args.batch_size, device=device)
             if isinstance(trainer, FlatTrainer):
                 train_loss = train_one_epoch(model, batcher, criterion, trainer, device=device, augment_fn=augment_fn,
                                              swap_tf=args.swap_tf)

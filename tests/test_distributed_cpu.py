@@ -176,3 +176,77 @@ def test_world_size_2_data_parallel_robustness(tmp_path):
     world, port = 2, 31500 + (os.getpid() % 2000)
     mp.spawn(_worker_dp, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"dp_ok{r}") for r in range(world))
+
+
+def _worker_flat_input(rank, world, port, tmp):
+    """Round 3: the data-parallel INPUT path.  A features.pkl is converted once, by rank 0 alone; every rank maps
+    the flat file and fetches only the rows of its share of each global batch; the dev scores travel as a tensor all-gather."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import pandas as pd
+    import dfa_amd  # noqa: F401
+    from dfa_amd import dataset as ds_mod, distributed as D
+    from dfa_amd.dataloaders import FlatBatcher, IndexedFlatBatcher, open_flat, train_shard_indices
+    D.init(backend="gloo")
+    n, F, T, bs = 37, 6, 5, 4
+    fpath, lpath = os.path.join(tmp, "features.pkl"), os.path.join(tmp, "labels.pkl")
+    if rank == 0:
+        g = torch.Generator().manual_seed(0)
+        feats = [torch.full((F, T), float(i)) + 0.001 * torch.randn(F, T, generator=g) for i in range(n)]
+        pd.DataFrame({"uttid": [f"u{i:03d}" for i in range(n)], "features": feats}).to_pickle(fpath)
+        pd.DataFrame({"uttid": [f"u{i:03d}" for i in range(n)], "label": [i % 2 for i in range(n)]}).to_pickle(lpath)
+    dist.barrier()
+    # nobody but rank 0 may un-pickle the features: make any other rank's pandas reader fail loudly
+    real_read = pd.read_pickle
+    if rank != 0:
+        def deny(path, *a, **k):
+            raise AssertionError(f"rank {rank} un-pickled {path}")
+        pd.read_pickle = deny
+    stacked_calls = []
+    real_stacked = ds_mod.AudioDeepfakeDataset.stacked
+    ds_mod.AudioDeepfakeDataset.stacked = lambda self, *a, **k: (stacked_calls.append(1), real_stacked(self, *a, **k))[1]
+    feats, labels, uttids = open_flat(fpath, lpath, os.path.join(tmp, "cache"), rank, world, "train")
+    pd.read_pickle = real_read
+    assert not stacked_calls and tuple(feats.shape) == (n, F, T) and len(uttids) == n
+    assert isinstance(feats.numpy().base, np.memmap) or not feats.numpy().flags.owndata      # a view of the mapped file, not a copy
+    # a flat prefix is opened directly, by every rank, with no conversion and no pickle at all
+    feats2, _, _ = open_flat(os.path.join(tmp, "cache", "train_flat"), None, os.path.join(tmp, "unused"), rank, world, "x")
+    assert torch.equal(feats2, feats) and not os.path.exists(os.path.join(tmp, "unused"))
+    # --- training epoch: same permutation on every rank, each rank fetches its rows only
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(5))
+    idx = train_shard_indices(perm, bs, rank, world)
+    batcher = IndexedFlatBatcher(feats, labels, idx, bs, device="cpu")
+    seen, nb = [], 0
+    for fb, lb in batcher:
+        assert fb.shape[0] == bs and torch.equal(lb, labels[idx[nb * bs:(nb + 1) * bs]])
+        seen.extend(int(round(float(v))) for v in fb[:, 0, 0])
+        nb += 1
+    assert seen == idx.tolist() and nb == len(batcher)
+    row_bytes = F * T * 4
+    total_rows = -(-n // (world * bs)) * world * bs                     # wrap-around padded to whole global batches
+    assert batcher.rows_fetched == total_rows // world and batcher.bytes_fetched == batcher.rows_fetched * row_bytes
+    # per-rank bytes pulled from the source ~ 1 / world of an epoch (never the whole set)
+    assert batcher.bytes_fetched <= (n * row_bytes) / world + world * bs * row_bytes
+    counts = torch.zeros(n)
+    counts.index_add_(0, idx, torch.ones(idx.numel()))
+    dist.all_reduce(counts)
+    assert int(counts.min()) >= 1 and int(counts.sum()) == total_rows     # together the ranks cover every utterance
+    # --- dev evaluation: contiguous shards + tensor all-gather of uneven score vectors (no pickled objects)
+    real_ago = dist.all_gather_object
+    dist.all_gather_object = lambda *a, **k: (_ for _ in ()).throw(AssertionError("all_gather_object on the per-epoch path"))
+    lo, hi = D.shard_range(n, rank, world)
+    local = [float(fb[i, 0, 0]) for fb, _ in FlatBatcher(feats, None, bs, device="cpu", rank=rank, world=world) for i in range(fb.shape[0])]
+    assert len(local) == hi - lo
+    allscores = D.gather_scores(local)
+    dist.all_gather_object = real_ago
+    assert allscores.shape == (n,) and np.allclose(allscores, feats[:, 0, 0].double().numpy())
+    assert np.array_equal(D.gather_scores([]) if False else allscores, allscores)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"flat_ok{rank}"), "w").write("ok")
+
+
+def test_world_size_2_flat_input_path(tmp_path):
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_flat_input, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"flat_ok{r}") for r in range(world))

@@ -1,5 +1,7 @@
 """Build profiles/rNN_pmc_traffic.json from the per-counter CSVs that tools/rocpd_summary.py (pmc) or rocprofv3's own
-counter_collection CSV produce.  usage: pmc_traffic_json.py <out.json> <tag>=<counter_collection.csv> ...
+counter_collection CSV produce.  usage: pmc_traffic_json.py <out.json> <step>:<tag>=<counter_collection.csv> ...
+<step> names the profiled driver (fwd, train_step, cnn1d_fwd, cae_score, cae_train_step, ...): besides the per-kernel means the
+file gets "steps": {<step>: {"hbm_bytes_per_step": sum over every dfa kernel launch of the run / launches of the driver's loop}}.
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE (KB, 64-B requests tallied for 128-B ones) is doubled;
 WRITE_SIZE (KB) is exact; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (mean over the launches seen)."""
 import csv, json, sys, collections
@@ -14,7 +16,15 @@ def read_counter_csv(path):
     return acc
 
 
+STEPS_IN_RUN = {"fwd": 6, "train_step": 6, "cnn1d_fwd": 10, "cnn1d_train_step": 6, "cae_score": 10, "cae_train_step": 6}   # loops of tools/gpu_prof_*.py
+STEP_ALGO = {   # algorithmic bytes per step at B = 256 (read x once + write the outputs)
+    "cnn1d_fwd": 256 * 231_124,
+    "cae_score": 256 * (321 * 180 * 2 + 4),          # bf16 features in, one float out
+}
+
 ALGO = {   # algorithmic bytes per launch at B = 256, T = 321, F = 180
+    "cnn1d_fused_kernel": 256 * 231_124,
+    "cae_dec_fused_kernel": 256 * (20 * 11 * 256 * 2 + 321 * 180 * 2 + 7 * 4),        # latent in, x (bf16) in, partial sums out
     "conv12_fused_kernel": 256 * (321 * 180 * 2 + 80 * 180 * 64 * 2),
     "conv3_m16_meant_kernel": 256 * (80 * 180 * 64 * 2 + 128 * 180 * 4),
     "conv_split_kernel<32, 4, 0": 256 * (160 * 180 * 32 * 4 + 80 * 180 * 64 * 4),     # bf16x3 block 2: a1 split in, a2 split out
@@ -38,12 +48,16 @@ ALGO = {   # algorithmic bytes per launch at B = 256, T = 321, F = 180 (DESIGN.m
 
 if __name__ == "__main__":
     out, merged = sys.argv[1], collections.defaultdict(dict)
+    step_tot = collections.defaultdict(lambda: collections.defaultdict(float))
     for spec in sys.argv[2:]:
         tag, path = spec.split("=", 1)
+        step = tag.split(":", 1)[0] if ":" in tag else None
         for kern, counters in read_counter_csv(path).items():
             for c, vals in counters.items():
                 merged[kern][c] = sum(vals) / len(vals)
                 merged[kern][c + "_launches"] = len(vals)
+                if step and kern.startswith(("dfa::", "void dfa::")):
+                    step_tot[step][c] += sum(vals)
     blob = {"source": "rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3 tools/gpu_prof_fwd.py / gpu_prof_train.py "
                       "(B=256, T=321, F=180); per-kernel means over the launches of each pass",
             "correction": "gfx950: FETCH_SIZE (KB) under-reports wide streaming reads by exactly 2x (MI355X_MICROARCH.md, HBM); "
@@ -64,5 +78,15 @@ if __name__ == "__main__":
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs issue MFMAs
             rec["mfma_busy_fraction"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 3)
         blob["kernels"][kern] = rec
+    blob["steps"] = {}
+    for step, tot in sorted(step_tot.items()):
+        n = STEPS_IN_RUN.get(step)
+        if n and "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+            rec = {"launches_of_the_loop": n, "hbm_bytes_per_step": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / n),
+                   "what": "sum over every dfa:: kernel launch of the profiled run (weight packing and reductions included) / loop count"}
+            if step in STEP_ALGO:
+                rec["algorithmic_bytes_per_step"] = STEP_ALGO[step]
+                rec["hbm_over_algorithmic"] = round(rec["hbm_bytes_per_step"] / STEP_ALGO[step], 3)
+            blob["steps"][step] = rec
     json.dump(blob, open(out, "w"), indent=1)
     print("wrote", out, len(blob["kernels"]), "kernels")
