@@ -247,10 +247,13 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
   };
 
   auto iteration = [&](auto ph_c, int it) { unit(ph_c, it); };      // (DMA issue, DMA wait and the barrier are inside the unit)
-  f32x4_t* const tot = (f32x4_t*)(smem + RING_BYTES + BIAS_BYTES) + tid * 4;   // eval: total over the canonical chunks
+  // eval: total over the canonical chunks.  Element k of thread tid lives at [k][tid] (16-byte stride between lanes): the
+  // [tid][k] order of round 2 put lanes 64 B apart, a 4-way bank conflict on every ds_read/write_b128 -- the source of block 3's
+  // SQ_LDS_BANK_CONFLICT (4.4 M of 55 M LDS cycles, profiles/r02_sq_summary.csv; the fragment reads are conflict-free).
+  f32x4_t* const tot = (f32x4_t*)(smem + RING_BYTES + BIAS_BYTES) + tid;
   if constexpr (!TRAIN) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tot[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k) tot[k * NT] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
   // outer loop over the canonical chunks of the time mean (chunk_iters iterations, a multiple of 6; one chunk = the whole
   // walk when unset), inner loop = the ring walk itself, unchanged; a chunk's sum is flushed once, outside the hot loop
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
         for (int ca = 0; ca < 2; ++ca)
 #pragma unroll
-          for (int pb = 0; pb < 2; ++pb) tot[ca * 2 + pb] += cs[ca][pb];
+          for (int pb = 0; pb < 2; ++pb) tot[(ca * 2 + pb) * NT] += cs[ca][pb];
       }
 #pragma unroll
       for (int ca = 0; ca < 2; ++ca)
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv3_m16_meant_kernel(ConvArgs a) {
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
-      const f32x4_t tv = tot[ca * 2 + pb];
+      const f32x4_t tv = tot[(ca * 2 + pb) * NT];
       if (16 * pb + p < SW && col < W) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

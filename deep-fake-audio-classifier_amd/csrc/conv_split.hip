@@ -330,8 +330,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
     }
   };
   // MEAN_T: running total over the canonical chunks of the time mean (ConvArgs::chunk_iters), 8 floats per lane in LDS
-  f32x4_t* const tot = (f32x4_t*)(smem + C::RING_BYTES + COUT * 4) + tid * 2;
-  if constexpr (EPI == SPLIT_EPI_MEAN_T) tot[0] = tot[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int TOT_STRIDE = NT;
+  f32x4_t* const tot = (f32x4_t*)(smem + C::RING_BYTES + COUT * 4) + tid;   // element k at [k][tid]: conflict-free b128 accesses (conv3_m16.hip)
+  if constexpr (EPI == SPLIT_EPI_MEAN_T) tot[0] = tot[TOT_STRIDE] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int chunk = (EPI == SPLIT_EPI_MEAN_T && a.chunk_iters > 0) ? a.chunk_iters : niter_all + 3;
   for (int c0 = it0; c0 < niter; c0 += chunk) {          // canonical chunks of the time mean; the inner loop is the ring walk
     const int cend = min(niter, c0 + chunk);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
         }
       } else {
         tot[0] += cs[0];
-        tot[1] += cs[1];
+        tot[TOT_STRIDE] += cs[1];
       }
       cs[0] = cs[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
       const int col = f0 + 16 * pb + p;
-      const f32x4_t tv = tot[pb];
+      const f32x4_t tv = tot[pb * TOT_STRIDE];
       if (col < W && 16 * pb + p < SW) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

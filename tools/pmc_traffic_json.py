@@ -23,7 +23,7 @@ STEP_ALGO = {   # algorithmic bytes per step at B = 256 (SURVEY.md section 8(d):
 }
 
 ALGO = {   # algorithmic bytes per launch at B = 256, T = 321, F = 180
-    "cnn1d_fused_kernel": 256 * 231_124,
+    "cnn1d_fused_kernel<": 256 * 231_124,
     "cae_dec_fused_kernel": 256 * (20 * 11 * 256 * 2 + 321 * 180 * 2 + 7 * 4),        # latent in, x (bf16) in, partial sums out
     "conv12_fused_kernel": 256 * (321 * 180 * 2 + 80 * 180 * 64 * 2),
     "conv3_m16_meant_kernel": 256 * (80 * 180 * 64 * 2 + 128 * 180 * 4),
