@@ -219,7 +219,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_dec_fused") == 0) { ctx->cae_dec_fused = value ? 1 : 0; return DFA_OK; }
-  if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value < 0 ? 0 : (value > 2 ? 1 : value); return DFA_OK; }
   if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "fuse_conv1") == 0) { ctx->fuse_conv1 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "lds_pipe") == 0) { ctx->lds_pipe = value ? 1 : 0; return DFA_OK; }
@@ -476,8 +476,9 @@ int dfa_cnn1d_prepare(dfa_ctx* ctx) {
   size_t off[3], boff[3], total = 0;
   for (int l = 0; l < 3; ++l) { off[l] = total; total = align_up(total + (size_t)cout[l] * cin[l] * 3 * 4, 256); }
   for (int l = 0; l < 3; ++l) { boff[l] = total; total = align_up(total + (size_t)cout[l] * 4, 256); }
-  size_t poff[3];
+  size_t poff[3], xoff[3];
   for (int l = 0; l < 3; ++l) { poff[l] = total; total = align_up(total + cnn1d_fused_pack_floats(cin[l], cout[l], l) * 4, 256); }
+  for (int l = 0; l < 3; ++l) { xoff[l] = total; total = align_up(total + cnn1d_x3_pack_bytes(cin[l], cout[l]), 256); }
   if (m.packed) { DFA_HIP_CHECK(ctx, hipFree(m.packed)); m.packed = nullptr; }
   DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, total));
   for (int l = 0; l < 3; ++l) {
@@ -487,6 +488,8 @@ int dfa_cnn1d_prepare(dfa_ctx* ctx) {
     DFA_HIP_CHECK(ctx, launch_fold_conv1d(q[0], q[1], q[2], q[3], q[4], q[5], m.w[l], m.b[l], cin[l], cout[l], ctx->stream));
     m.wp[l] = (float*)((char*)m.packed + poff[l]);
     DFA_HIP_CHECK(ctx, launch_pack_cnn1d_fused(m.w[l], m.wp[l], cin[l], cout[l], l, ctx->stream));
+    m.wx[l] = (char*)m.packed + xoff[l];
+    DFA_HIP_CHECK(ctx, launch_pack_cnn1d_x3(m.w[l], m.wx[l], cin[l], cout[l], ctx->stream));
   }
   m.prepared = true;
   return DFA_OK;
@@ -510,6 +513,12 @@ int dfa_cnn1d_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
   hipStream_t s = ctx->stream;
   // (the fused kernel addresses an utterance's elements with 32-bit offsets)
   const bool off32 = stride_t >= 0 && stride_f >= 0 && (int64_t)(F - 1) * stride_f + (int64_t)(T - 1) * stride_t < ((int64_t)1 << 31);
+  if (ctx->cnn1d_fused == 1 && cnn1d_fused_x3_supports(x, stride_b, stride_t, stride_f, T, F)) {   // split-bf16 matrix cores (slot 4)
+    ScopedSlot ts(ctx, 4);
+    DFA_HIP_CHECK(ctx, launch_cnn1d_fused_x3((const float*)x, m.wx[0], m.b[0], m.wx[1], m.b[1], m.wx[2], m.b[2], m.p[18], m.p[19], logits, B, T, F,
+                                             s, ctx->clock_probe ? ctx->clock_buf : nullptr));
+    return DFA_OK;
+  }
   if (ctx->cnn1d_fused && cnn1d_fused_supports(T) && off32) {   // one kernel, one global write per utterance (timing slot 4)
     ScopedSlot ts(ctx, 4);
     DFA_HIP_CHECK(ctx, launch_cnn1d_fused((const float*)x, stride_b, stride_t, stride_f, m.wp[0], m.b[0], m.wp[1], m.b[1], m.wp[2], m.b[2],

@@ -1,0 +1,406 @@
+// cnn1d_fused_x3.hip -- the CNN1D eval forward (src/model_cnn1d.py:37-46) as ONE kernel on the bf16 matrix cores at fp32-grade
+// accuracy: every weight and activation is carried as hi + lo bf16 (16 significant bits), every product is three
+// v_mfma_f32_32x32x16_bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate; the dropped lo*lo term is 2^-18 of a product) -- the
+// DFA_PREC_BF16X3 construction of conv_split.hip.  The exact-fp32 form (cnn1d_fused.hip, v_mfma_f32_32x32x2_f32) is held at
+// ~80 cycles per 2048 MACs by the fp32 matrix pipe (2172 MFMAs = 174 k cycles per utterance, 85 us per 256 utterances); the same
+// MACs cost 3 x 32 cycles per 16384 here, so the kernel is bound by moving and splitting x instead.
+//   * workgroup = one utterance, 4 waves; x is read ONCE with aligned 16-byte loads: the reference stores [F][T] contiguously
+//     (src/dataset.py:52), so 16 input channels = one contiguous, 16-byte aligned slab of 16 T floats; slabs are double-buffered
+//     in LDS as they are (fp32, [channel][frame]) and the lane that owns frame t reads x[c][t-1 .. t+1] for its 8 channels as
+//     conflict-free ds_read_b32 -- the three conv taps of a k-step from one set of reads;
+//   * the values are split into hi / lo bf16 in registers and ARE the B fragments (lane = frame, 8 consecutive channels per
+//     lane half): layer 1 needs no transposed image at all.  Its weights (72 KB of A fragments) sit in LDS for the layer;
+//   * h1 [T][32] and h2 [T][64] live in LDS channels-last as [hi: C bf16][lo: C bf16] pixels with the chunk swizzle of
+//     conv3x3_mfma.h, written from the accumulator layout as 8-byte stores (4 consecutive channels of one frame per lane),
+//     read as ds_read_b128 fragments at frame t + tap - 1; layers 2 and 3 keep their hi / lo A fragments in registers;
+//   * frame mean and the 128 -> 1 classifier in the epilogue, as in cnn1d_fused.hip: logits[b] is the only global write.
+// LDS: region A = two x slabs during layer 1, then h1; region B = layer-1 weights, then h2 (136 KB at T = 321).
+// Takes the reference's storage only (x[b][f][t] contiguous, 16-byte aligned, F % 4 == 0, 3 <= T <= 384); anything else runs
+// cnn1d_fused.hip / the three-launch path (api.hip).
+#include "dfa_internal.h"
+#include "conv3x3_mfma.h"
+
+namespace dfa {
+namespace c1x {
+constexpr int TW = 32, MAXT1 = 3;
+}
+
+// A-fragment images: wx[m][tap][ks][part][lane] (uint4), part 0 = hi, 1 = lo; lane: co = 32 m + (lane & 31), element j <-> input
+// channel 16 ks + 8 (lane >> 5) + j (zero beyond cin).  wf = BN-folded fp32 weights [cout][cin][3].
+__global__ void pack_cnn1d_x3_kernel(const float* __restrict__ wf, uint4* __restrict__ wx, int cin, int cout, int nks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int total = (cout / 32) * 3 * nks * 64;
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int ks = rest % nks; rest /= nks;
+  const int tap = rest % 3, m = rest / 3;
+  const int co = 32 * m + (lane & 31), hh = lane >> 5;
+  bf16_t hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = 16 * ks + 8 * hh + j;
+    const float w = ci < cin ? wf[((size_t)co * cin + ci) * 3 + tap] : 0.f;
+    hi[j] = float_to_bf16(w);
+    lo[j] = float_to_bf16(w - bf16_to_float(hi[j]));
+  }
+  uint4* dst = wx + ((size_t)((m * 3 + tap) * nks + ks) * 2) * 64 + lane;
+  dst[0] = *reinterpret_cast<const uint4*>(hi);
+  dst[64] = *reinterpret_cast<const uint4*>(lo);
+}
+
+// k-steps of 16 input channels; layer 1 (the only layer with cin != 32, 64) runs its slabs two per loop trip: padded to an even count
+int cnn1d_x3_nks(int cin) { const int n = (cin + 15) / 16; return (cin == 32 || cin == 64) ? n : (n + 1) & ~1; }
+size_t cnn1d_x3_pack_bytes(int cin, int cout) { return (size_t)(cout / 32) * 3 * cnn1d_x3_nks(cin) * 2 * 64 * 16; }
+hipError_t launch_pack_cnn1d_x3(const float* wf, void* wx, int cin, int cout, hipStream_t s) {
+  const int total = (cout / 32) * 3 * cnn1d_x3_nks(cin) * 64;
+  hipLaunchKernelGGL(pack_cnn1d_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, wf, (uint4*)wx, cin, cout, cnn1d_x3_nks(cin));
+  return hipGetLastError();
+}
+
+struct Cnn1dX3Args {
+  const float* x;              // [B][F][T] contiguous, 16-byte aligned
+  const uint4 *w1, *w2, *w3;   // hi / lo A-fragment images of the three layers
+  const float *b1, *b2, *b3, *cw, *cb;
+  float* logits;
+  int T, F, NT, nks1;          // NT = ceil(T / 32), nks1 = ceil(F / 16)
+  int offA_h1, offB;           // LDS byte offsets: region A = [0, offB) (slabs / h1), region B = [offB, ...) (W1 / h2)
+  int slab_floats;             // 16 T + 8
+  long long* stamps;
+};
+
+__device__ __forceinline__ f32x16_t mma_bf16(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// 8 floats -> hi / lo bf16 fragments (element j in bf16 position j)
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    h[p] = pack_bf16x2(v[2 * p], v[2 * p + 1]);
+    l[p] = pack_bf16x2(v[2 * p] - __uint_as_float(h[p] << 16), v[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ uint4 and4(unsigned m, const uint4& v) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); }   // (a select here became an exec branch)
+
+// one 32-frame tile of a layer whose input lives in LDS as split pixels: acc = sum over (tap, ks) of the three split products.
+// PB = pixel bytes (4 * CIN), NKS = CIN / 16; lane reads pixel slot t + tap, chunks 2 ks + h (hi) and CIN / 8 + 2 ks + h (lo).
+// The fragment reads run PD steps ahead of their MFMAs through a rotating register queue and `side(i)` -- a slice of the PREVIOUS
+// tile's epilogue -- is issued in the shadow of step i's three MFMAs; sched_barrier pins that order (left alone, hipcc puts each
+// ds_read_b128 directly in front of its MFMA and the whole epilogue between two tiles: stamps showed layers 2 / 3 at 3.6x / 2.1x
+// their matrix-pipe time).
+template <int CIN, typename Side>
+__device__ __forceinline__ void split_gemm(const uint4 (&wh)[3 * (CIN / 16)], const uint4 (&wl)[3 * (CIN / 16)], const char* img, int t0,
+                                           int col, int h, f32x16_t& acc, Side side) {
+  constexpr int PB = 4 * CIN, NKS = CIN / 16, NS = 3 * NKS, PD = 3;
+  const char* px[3];
+  int sw[3];
+#pragma unroll
+  for (int tap = 0; tap < 3; ++tap) {
+    const int slot = t0 + col + tap;
+    sw[tap] = lds_swz<PB>(slot);
+    px[tap] = img + slot * PB;
+  }
+  uint4 qh[PD], ql[PD];
+  auto rd = [&](int i, uint4& xh, uint4& xl) {
+    const int tap = i / NKS, ks = i % NKS;
+    xh = *(const uint4*)(px[tap] + (((2 * ks + h) ^ sw[tap]) << 4));
+    xl = *(const uint4*)(px[tap] + (((CIN / 8 + 2 * ks + h) ^ sw[tap]) << 4));
+  };
+#pragma unroll
+  for (int i = 0; i < PD; ++i) rd(i, qh[i], ql[i]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const uint4 xh = qh[i % PD], xl = ql[i % PD];
+    if (i + PD < NS) rd(i + PD, qh[i % PD], ql[i % PD]);
+    acc = mma_bf16(wh[i], xh, acc);
+    acc = mma_bf16(wl[i], xh, acc);
+    acc = mma_bf16(wh[i], xl, acc);
+    side(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// bias + ReLU + hi / lo split of one accumulator -> the split image of the next layer (COUT channels per pixel); frames >= T are
+// stored as zeros (the next layer's right-hand padding); lane = frame, registers 4 g .. 4 g + 3 = channels co0 + 8 g + 4 h + (0..3)
+template <int COUT>
+__device__ __forceinline__ void store_split_g(const f32x16_t& acc, const float* bias, int co0, char* img, int t, int T, int h, int g) {
+  constexpr int PB = 4 * COUT;
+  const int slot = t + 1, sw = lds_swz<PB>(slot);
+  char* px = img + slot * PB;
+  const int co = co0 + 8 * g + 4 * h;
+  const float4 bv = *(const float4*)(bias + co);
+  float v[4] = {fmaxf(acc[4 * g] + bv.x, 0.f), fmaxf(acc[4 * g + 1] + bv.y, 0.f), fmaxf(acc[4 * g + 2] + bv.z, 0.f), fmaxf(acc[4 * g + 3] + bv.w, 0.f)};
+  if (t >= T) v[0] = v[1] = v[2] = v[3] = 0.f;
+  const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+  const unsigned l0 = pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+  const unsigned l1 = pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+  const int c = co >> 3;
+  *(uint2*)(px + ((c ^ sw) << 4) + 8 * h) = make_uint2(h0, h1);
+  *(uint2*)(px + (((COUT / 8 + c) ^ sw) << 4) + 8 * h) = make_uint2(l0, l1);
+}
+template <int COUT>
+__device__ __forceinline__ void store_split(const f32x16_t& acc, const float* bias, int co0, char* img, int t, int T, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) store_split_g<COUT>(acc, bias, co0, img, t, T, h, g);
+}
+
+__global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
+  using namespace c1x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x;
+  const int T = a.T, NT = a.NT;
+  const int nslots = 32 * NT + 2;
+  float* const slab0 = (float*)smem;                      // two slabs of slab_floats floats: [4 pad][16 x T][4 pad]
+  char* const h1S = smem;                                 // region A again, after layer 1: [nslots][128 B]
+  char* const w1S = smem + a.offB;                        // region B: layer-1 A fragments [3][nks1][2][64] x 16 B ...
+  char* const h2S = smem + a.offB;                        // ... then h2 [nslots][256 B]
+  float* const red = (float*)(smem + a.offB + nslots * 256);
+  const bool stamp = a.stamps != nullptr && tid == 0 && b < 128;
+  if (stamp) { a.stamps[8 * b] = __builtin_amdgcn_s_memtime(); a.stamps[8 * b + 5] = __builtin_amdgcn_s_memrealtime(); }
+
+  // hi / lo weight fragments of layers 2 and 3 (48 + 96 registers), requested first
+  uint4 w2h[6], w2l[6], w3h[12], w3l[12];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    w2h[i] = a.w2[((size_t)((wave & 1) * 6 + i) * 2) * 64 + lane];
+    w2l[i] = a.w2[((size_t)((wave & 1) * 6 + i) * 2 + 1) * 64 + lane];
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    w3h[i] = a.w3[((size_t)(wave * 12 + i) * 2) * 64 + lane];
+    w3l[i] = a.w3[((size_t)(wave * 12 + i) * 2 + 1) * 64 + lane];
+  }
+
+  // ------------------------------------------------------------------------------------------------ layer 1: F -> 32
+  const int nks1 = a.nks1;
+  f32x16_t acc1[MAXT1];
+  {
+    const float4* xg = (const float4*)(a.x + (size_t)b * a.F * T);
+    const int SL = a.slab_floats;
+    constexpr int NLD = 6;                                   // 16 T / 4 float4 per slab <= 1536 = 6 x 256
+    float4 xrA[NLD], xrB[NLD];                                // two slabs in flight: a slab has two loop trips (~4 k cycles) to land
+    // Loads are unconditional (clamped index) and the zero fill of a short last slab happens at store time: a conditional load is
+    // an exec branch, and hipcc's vmcnt bookkeeping across a branch is conservative (seen in the ISA: vmcnt(0) behind every load).
+    const int nreal = (a.F + 15) / 16;                        // slabs that exist (nks1 may be one more: a zero slab)
+    auto slab_n4 = [&](int s) { return max(0, min(16, a.F - 16 * s)) * T / 4; };
+    auto slab_load = [&](int s, float4 (&xr)[NLD]) {          // slab s = channels 16 s .. (one contiguous run of rows * T floats)
+      const int sc = min(s, nreal - 1), n4 = slab_n4(sc);
+      const float4* src = xg + (size_t)4 * sc * T;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) xr[k] = src[min(k * 256 + tid, n4 - 1)];
+    };
+    auto slab_store = [&](int s, const float4 (&xr)[NLD]) {
+      float* dst = slab0 + (s & 1) * SL + 4;
+      const int n4 = slab_n4(s);                              // channels a short (or padded) last slab does not have become zeros
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = k * 256 + tid;
+        const unsigned m = i < n4 ? 0xffffffffu : 0u;
+        const float4 v = xr[k];
+        if (i < 4 * T)
+          *(uint4*)(dst + 4 * i) = make_uint4(__float_as_uint(v.x) & m, __float_as_uint(v.y) & m, __float_as_uint(v.z) & m, __float_as_uint(v.w) & m);
+      }
+    };
+    slab_load(0, xrA);
+    slab_load(1, xrB);
+    // layer-1 A fragments -> LDS (contiguous copy), pads of the two slabs
+    {
+      const int n = 3 * nks1 * 2 * 64;
+      for (int i = tid; i < n; i += 256) *(uint4*)(w1S + (size_t)i * 16) = a.w1[i];
+      if (tid < 16) {
+        const int sb = tid >> 3, e = tid & 7;
+        slab0[sb * SL + (e < 4 ? e : 16 * T + e)] = 0.f;
+      }
+    }
+    slab_store(0, xrA);
+    __syncthreads();
+
+    const int nmine = (NT - wave + 3) / 4;
+    unsigned tin[MAXT1][3];                                  // all-ones where tap k of this lane's frame exists, else 0
+    int tl[MAXT1];
+#pragma unroll
+    for (int j = 0; j < MAXT1; ++j) {
+      const int t = TW * (wave + 4 * j) + col;
+      tl[j] = t;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tin[j][k] = ((j < nmine) && t < T && t - 1 + k >= 0 && t - 1 + k < T) ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+    }
+    // one slab = one k-step of 16 channels: trip s computes slab s from buffer s & 1, requests slab s + 2 and parks slab s + 1
+    // (requested a trip ago) in the other buffer; one barrier per trip
+    auto trip = [&](int s, float4 (&xr_next)[NLD], float4 (&xr_far)[NLD], bool load) {
+      if (load) slab_load(s + 2, xr_far);                     // (compile-time after inlining: the steady loop loads, the two tail trips do not)
+      const float* sl = slab0 + (s & 1) * SL + 4 + 8 * h * T - 1;       // this lane half's 8 channels, frame index - 1
+      uint4 wh[3], wl[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        wh[k] = *(const uint4*)(w1S + ((size_t)((k * nks1 + s) * 2) * 64 + lane) * 16);
+        wl[k] = *(const uint4*)(w1S + ((size_t)((k * nks1 + s) * 2 + 1) * 64 + lane) * 16);
+      }
+      float va[3][8], vb[3][8];
+      auto rdv = [&](int j, float (&v)[3][8]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v[k][c] = sl[c * T + tl[j] + k];
+      };
+      auto mm = [&](int j, const float (&v)[3][8]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          uint4 xh, xl;
+          split8(v[k], xh, xl);
+          xh = and4(tin[j][k], xh);
+          xl = and4(tin[j][k], xl);
+          acc1[j] = mma_bf16(wh[k], xh, acc1[j]);
+          acc1[j] = mma_bf16(wl[k], xh, acc1[j]);
+          acc1[j] = mma_bf16(wh[k], xl, acc1[j]);
+        }
+      };
+      rdv(0, va);
+      __builtin_amdgcn_sched_barrier(0);
+      rdv(1, vb);
+      mm(0, va);
+      __builtin_amdgcn_sched_barrier(0);
+      rdv(2, va);
+      mm(1, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(2, va);
+      __builtin_amdgcn_sched_barrier(0);
+      slab_store(s + 1, xr_next);
+      __syncthreads();
+    };
+    int s = 0;
+    for (; s + 2 < nks1; s += 2) {                            // nks1 is even: no branch in the steady loop
+      trip(s, xrB, xrA, true);
+      trip(s + 1, xrA, xrB, true);
+    }
+    trip(s, xrB, xrA, false);
+    trip(s + 1, xrA, xrB, false);
+  }
+  if (stamp) a.stamps[8 * b + 1] = __builtin_amdgcn_s_memtime();
+  // (the barrier that closed the loop: every wave is done with the slabs and the layer-1 weights)
+  {
+    // h1 halo: slot 0 (frame -1); frames >= T are written as zeros by the epilogue below, slot 32 NT + 1 here
+    if (tid < 16) *(uint4*)(h1S + (tid < 8 ? 0 : (nslots - 1) * 128) + (tid & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    const int nmine = (NT - wave + 3) / 4;
+#pragma unroll
+    for (int j = 0; j < MAXT1; ++j)
+      if (j < nmine) store_split<32>(acc1[j], a.b1, 0, h1S, TW * (wave + 4 * j) + col, T, h);
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------------------------------------ layer 2: 32 -> 64
+  {
+    const int m = wave & 1, par = wave >> 1;
+    if (tid < 32) *(uint4*)(h2S + (tid < 16 ? 0 : (nslots - 1) * 256) + (tid & 15) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // tile i's bias + ReLU + split + store rides on tile i + 1's steps (one 4-channel group per step)
+    f32x16_t accA, accB;
+    int tile = par;
+    if (tile < NT) {
+      split_gemm<32>(w2h, w2l, h1S, TW * tile, col, h, accA, [](int) {});
+      for (tile += 2; tile + 2 < NT; tile += 4) {
+        split_gemm<32>(w2h, w2l, h1S, TW * tile, col, h, accB,
+                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accA, a.b2, 32 * m, h2S, TW * (tile - 2) + col, T, h, i - 1); });
+        split_gemm<32>(w2h, w2l, h1S, TW * (tile + 2), col, h, accA,
+                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accB, a.b2, 32 * m, h2S, TW * tile + col, T, h, i - 1); });
+      }
+      if (tile < NT) {
+        split_gemm<32>(w2h, w2l, h1S, TW * tile, col, h, accB,
+                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accA, a.b2, 32 * m, h2S, TW * (tile - 2) + col, T, h, i - 1); });
+        store_split<64>(accB, a.b2, 32 * m, h2S, TW * tile + col, T, h);
+      } else {
+        store_split<64>(accA, a.b2, 32 * m, h2S, TW * (tile - 2) + col, T, h);
+      }
+    }
+  }
+  __syncthreads();
+  if (stamp) a.stamps[8 * b + 2] = __builtin_amdgcn_s_memtime();
+
+  // ------------------------------------------------------------------------------------------------ layer 3: 64 -> 128, frame mean, classifier
+  {
+    const int m = wave;
+    float bias[16], sum[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bias[r] = a.b3[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h];
+      sum[r] = 0.f;
+    }
+    auto add_regs = [&](const f32x16_t& v, int tile, int r0) {       // two accumulator registers per step
+      const bool inside = TW * tile + col < T;
+#pragma unroll
+      for (int r = r0; r < r0 + 2; ++r) sum[r] += inside ? fmaxf(v[r] + bias[r], 0.f) : 0.f;
+    };
+    f32x16_t accA, accB;
+    split_gemm<64>(w3h, w3l, h2S, 0, col, h, accA, [](int) {});
+    int tile = 1;
+    for (; tile + 1 < NT; tile += 2) {
+      split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accB, [&](int i) { if (i >= 2 && i < 10) add_regs(accA, tile - 1, 2 * (i - 2)); });
+      split_gemm<64>(w3h, w3l, h2S, TW * (tile + 1), col, h, accA, [&](int i) { if (i >= 2 && i < 10) add_regs(accB, tile, 2 * (i - 2)); });
+    }
+    if (tile < NT) {
+      split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accB, [&](int i) { if (i >= 2 && i < 10) add_regs(accA, tile - 1, 2 * (i - 2)); });
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) add_regs(accB, tile, r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) add_regs(accA, tile - 1, r);
+    }
+    float part = 0.f;
+    const float inv_t = 1.0f / (float)T;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s = sum[r];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      part = fmaf(s * inv_t, a.cw[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h], part);
+    }
+    part += __shfl_xor(part, 32, 64);
+    if (lane == 0) red[wave] = part;
+  }
+  __syncthreads();
+  if (stamp) { a.stamps[8 * b + 3] = __builtin_amdgcn_s_memtime(); a.stamps[8 * b + 6] = __builtin_amdgcn_s_memrealtime(); }
+  if (tid == 0) a.logits[b] = ((red[0] + red[1]) + (red[2] + red[3])) + a.cb[0];
+}
+
+static void cnn1d_x3_layout(int T, int F, int* offB, int* total, int* slab_floats) {
+  const int NT = (T + 31) / 32, nslots = 32 * NT + 2, nks1 = cnn1d_x3_nks(F);
+  const int SL = 16 * T + 8;
+  const int regA = std::max(2 * SL * 4, nslots * 128);
+  const int regB = std::max(3 * nks1 * 2 * 64 * 16, nslots * 256);
+  *offB = (regA + 255) / 256 * 256;
+  *total = *offB + regB + 64;
+  *slab_floats = SL;
+}
+// x must be the contiguous [B][F][T] storage (element (b, t, f) at b F T + f T + t), 16-byte aligned
+bool cnn1d_fused_x3_supports(const void* x, int64_t sb, int64_t st, int64_t sf, int T, int F) {
+  if (T < 3 || (T + 31) / 32 > 4 * c1x::MAXT1 || F < 1 || (F & 3)) return false;
+  if (st != 1 || sf != T || sb != (int64_t)F * T || ((uintptr_t)x & 15)) return false;
+  int offB, total, sl;
+  cnn1d_x3_layout(T, F, &offB, &total, &sl);
+  return total <= 160 * 1024;
+}
+
+hipError_t launch_cnn1d_fused_x3(const float* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                                 const float* b3, const float* cw, const float* cb, float* logits, int B, int T, int F, hipStream_t s,
+                                 long long* stamps) {
+  Cnn1dX3Args a{};
+  a.x = x; a.w1 = (const uint4*)w1; a.w2 = (const uint4*)w2; a.w3 = (const uint4*)w3; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.cw = cw; a.cb = cb;
+  a.logits = logits; a.T = T; a.F = F; a.NT = (T + 31) / 32; a.nks1 = cnn1d_x3_nks(F); a.stamps = stamps;
+  int total;
+  cnn1d_x3_layout(T, F, &a.offB, &total, &a.slab_floats);
+  hipError_t e = hipFuncSetAttribute((const void*)cnn1d_fused_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cnn1d_fused_x3_kernel, dim3(B), dim3(256), total, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace dfa

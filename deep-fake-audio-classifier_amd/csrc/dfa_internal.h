@@ -65,6 +65,7 @@ struct Cnn1dState {
   void* packed = nullptr;
   float *w[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
   float* wp[3] = {nullptr, nullptr, nullptr};   // MFMA A-fragment images of the folded weights (cnn1d_fused.hip)
+  void* wx[3] = {nullptr, nullptr, nullptr};    // hi / lo bf16 A-fragment images (cnn1d_fused_x3.hip)
   // train mode: data-gradient weight images of conv layers 2 and 3 (+ a zero bias), dropout state
   void* train_packed = nullptr;
   float *wt[2] = {nullptr, nullptr}, *zero_bias = nullptr;
@@ -103,7 +104,8 @@ struct dfa_ctx {
   int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
-  int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel (cnn1d_fused.hip) when T <= 384; 0 = the three-launch path
+  int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel when T <= 384: 1 = split-bf16 kernel (cnn1d_fused_x3.hip) for the reference's
+                               // storage layout, the exact-fp32 one (cnn1d_fused.hip) otherwise; 2 = always the exact-fp32 one; 0 = the three-launch path
   int clock_probe = 0;         // 1 = the bf16 block-3 kernel stamps its main loop (s_memtime / s_memrealtime) into clock_buf: dfa_ctx_clock_read
   long long* clock_buf = nullptr;   // device, 1024 x {cycles, 100 MHz ticks}
   float* aug_keep = nullptr;        // device copy of the armed augmentation's keep mask (dfa_cnn2d_set_train_augment copies keep_f)
@@ -206,6 +208,14 @@ hipError_t launch_pack_cnn1d_fused(const float* wf, float* wp, int cin, int cout
 hipError_t launch_cnn1d_fused(const float* x, int64_t sb, int64_t st, int64_t sf, const float* wp1, const float* b1, const float* wp2,
                               const float* b2, const float* wp3, const float* b3, const float* cw, const float* cb, float* logits, int B,
                               int T, int F, hipStream_t s, long long* stamps = nullptr);
+// cnn1d_fused_x3.hip: the same forward on the bf16 matrix cores with hi + lo bf16 operands (fp32-grade accuracy)
+int cnn1d_x3_nks(int cin);
+size_t cnn1d_x3_pack_bytes(int cin, int cout);
+hipError_t launch_pack_cnn1d_x3(const float* wf, void* wx, int cin, int cout, hipStream_t s);
+bool cnn1d_fused_x3_supports(const void* x, int64_t sb, int64_t st, int64_t sf, int T, int F);
+hipError_t launch_cnn1d_fused_x3(const float* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                                 const float* b3, const float* cw, const float* cb, float* logits, int B, int T, int F, hipStream_t s,
+                                 long long* stamps = nullptr);
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
                          float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu = true);
 // train_cnn1d.hip

@@ -90,8 +90,11 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
  *   "cae_dec_fused" 1 (default) = auto-encoder eval forward in bf16 mode: the four decoder blocks, the zero time padding and the
  *                   per-sample squared error run as ONE kernel with the intermediates in LDS / registers; 0 = four launches
- *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel (all three Conv1d layers on the fp32 matrix cores with the
- *                   activations in LDS, the frame mean and the classifier in its epilogue) for T <= 384; 0 = the three-launch path
+ *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel for T <= 384 (all three Conv1d layers on the matrix cores with the
+ *                   activations in LDS, the frame mean and the classifier in its epilogue): hi + lo bf16 operands, three bf16 MFMAs
+ *                   per product (fp32-grade: logits within 1e-4 of the reference) when x is the reference's contiguous [B,F,T]
+ *                   storage, the exact-fp32 matrix-core kernel for any other strides; 2 = always the exact-fp32 kernel; 0 = the
+ *                   three-launch path
  *   "clock_probe"   1 = the dominant kernel of the bf16 eval forward (CNN2D block 3) brackets its main loop with s_memtime /
  *                   s_memrealtime stamps (lane 0 of the first 1024 workgroups, into a buffer no kernel reads); dfa_ctx_clock_read
  *                   returns the shader clock the chip held inside that kernel.  0 (default) = two scalar compares per workgroup
