@@ -4,7 +4,7 @@
 // DFA_PREC_BF16X3 construction of conv_split.hip.  The exact-fp32 form (cnn1d_fused.hip, v_mfma_f32_32x32x2_f32) is held at
 // ~80 cycles per 2048 MACs by the fp32 matrix pipe (2172 MFMAs = 174 k cycles per utterance, 85 us per 256 utterances); the same
 // MACs cost 3 x 32 cycles per 16384 here, so the kernel is bound by moving and splitting x instead.
-//   * workgroup = one utterance, 4 waves; x is read ONCE with aligned 16-byte loads: the reference stores [F][T] contiguously
+//   * workgroup = one utterance, 8 waves (two per SIMD); x is read ONCE with aligned 16-byte loads: the reference stores [F][T] contiguously
 //     (src/dataset.py:52), so 16 input channels = one contiguous, 16-byte aligned slab of 16 T floats; slabs are double-buffered
 //     in LDS as they are (fp32, [channel][frame]) and the lane that owns frame t reads x[c][t-1 .. t+1] for its 8 channels as
 //     conflict-free ds_read_b32 -- the three conv taps of a k-step from one set of reads;
@@ -22,7 +22,7 @@
 
 namespace dfa {
 namespace c1x {
-constexpr int TW = 32, MAXT1 = 3;
+constexpr int TW = 32, NW = 8, NTH = 64 * NW, MAXT1 = 2;   // 8 waves = two per SIMD (one wave's VALU / LDS work under the other's MFMAs); layer 1: tiles w, w + 8
 }
 
 // A-fragment images: wx[m][tap][ks][part][lane] (uint4), part 0 = hi, 1 = lo; lane: co = 32 m + (lane & 31), element j <-> input
@@ -94,7 +94,7 @@ __device__ __forceinline__ uint4 and4(unsigned m, const uint4& v) { return make_
 template <int CIN, typename Side>
 __device__ __forceinline__ void split_gemm(const uint4 (&wh)[3 * (CIN / 16)], const uint4 (&wl)[3 * (CIN / 16)], const char* img, int t0,
                                            int col, int h, f32x16_t& acc, Side side) {
-  constexpr int PB = 4 * CIN, NKS = CIN / 16, NS = 3 * NKS, PD = 3;
+  constexpr int PB = 4 * CIN, NKS = CIN / 16, NS = 3 * NKS, PD = CIN >= 64 ? 2 : 3;   // (layer 3 holds 96 weight registers: a shorter queue)
   const char* px[3];
   int sw[3];
 #pragma unroll
@@ -149,7 +149,7 @@ __device__ __forceinline__ void store_split(const f32x16_t& acc, const float* bi
   for (int g = 0; g < 4; ++g) store_split_g<COUT>(acc, bias, co0, img, t, T, h, g);
 }
 
-__global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
+__global__ __launch_bounds__(512) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
   using namespace c1x;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -166,26 +166,13 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
   const bool stamp = a.stamps != nullptr && tid == 0 && b < 128;
   if (stamp) { a.stamps[8 * b] = __builtin_amdgcn_s_memtime(); a.stamps[8 * b + 5] = __builtin_amdgcn_s_memrealtime(); }
 
-  // hi / lo weight fragments of layers 2 and 3 (48 + 96 registers), requested first
-  uint4 w2h[6], w2l[6], w3h[12], w3l[12];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    w2h[i] = a.w2[((size_t)((wave & 1) * 6 + i) * 2) * 64 + lane];
-    w2l[i] = a.w2[((size_t)((wave & 1) * 6 + i) * 2 + 1) * 64 + lane];
-  }
-#pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    w3h[i] = a.w3[((size_t)(wave * 12 + i) * 2) * 64 + lane];
-    w3l[i] = a.w3[((size_t)(wave * 12 + i) * 2 + 1) * 64 + lane];
-  }
-
   // ------------------------------------------------------------------------------------------------ layer 1: F -> 32
   const int nks1 = a.nks1;
   f32x16_t acc1[MAXT1];
   {
     const float4* xg = (const float4*)(a.x + (size_t)b * a.F * T);
     const int SL = a.slab_floats;
-    constexpr int NLD = 6;                                   // 16 T / 4 float4 per slab <= 1536 = 6 x 256
+    constexpr int NLD = 3;                                   // 16 T / 4 float4 per slab <= 1536 = 3 x 512
     float4 xrA[NLD], xrB[NLD];                                // two slabs in flight: a slab has two loop trips (~4 k cycles) to land
     // Loads are unconditional (clamped index) and the zero fill of a short last slab happens at store time: a conditional load is
     // an exec branch, and hipcc's vmcnt bookkeeping across a branch is conservative (seen in the ISA: vmcnt(0) behind every load).
@@ -195,14 +182,14 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
       const int sc = min(s, nreal - 1), n4 = slab_n4(sc);
       const float4* src = xg + (size_t)4 * sc * T;
 #pragma unroll
-      for (int k = 0; k < NLD; ++k) xr[k] = src[min(k * 256 + tid, n4 - 1)];
+      for (int k = 0; k < NLD; ++k) xr[k] = src[min(k * NTH + tid, n4 - 1)];
     };
     auto slab_store = [&](int s, const float4 (&xr)[NLD]) {
       float* dst = slab0 + (s & 1) * SL + 4;
       const int n4 = slab_n4(s);                              // channels a short (or padded) last slab does not have become zeros
 #pragma unroll
       for (int k = 0; k < NLD; ++k) {
-        const int i = k * 256 + tid;
+        const int i = k * NTH + tid;
         const unsigned m = i < n4 ? 0xffffffffu : 0u;
         const float4 v = xr[k];
         if (i < 4 * T)
@@ -214,7 +201,7 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
     // layer-1 A fragments -> LDS (contiguous copy), pads of the two slabs
     {
       const int n = 3 * nks1 * 2 * 64;
-      for (int i = tid; i < n; i += 256) *(uint4*)(w1S + (size_t)i * 16) = a.w1[i];
+      for (int i = tid; i < n; i += NTH) *(uint4*)(w1S + (size_t)i * 16) = a.w1[i];
       if (tid < 16) {
         const int sb = tid >> 3, e = tid & 7;
         slab0[sb * SL + (e < 4 ? e : 16 * T + e)] = 0.f;
@@ -223,12 +210,12 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
     slab_store(0, xrA);
     __syncthreads();
 
-    const int nmine = (NT - wave + 3) / 4;
+    const int nmine = (NT - wave + NW - 1) / NW;
     unsigned tin[MAXT1][3];                                  // all-ones where tap k of this lane's frame exists, else 0
     int tl[MAXT1];
 #pragma unroll
     for (int j = 0; j < MAXT1; ++j) {
-      const int t = TW * (wave + 4 * j) + col;
+      const int t = TW * (wave + NW * j) + col;
       tl[j] = t;
 #pragma unroll
       for (int k = 0; k < 3; ++k) tin[j][k] = ((j < nmine) && t < T && t - 1 + k >= 0 && t - 1 + k < T) ? 0xffffffffu : 0u;
@@ -270,10 +257,7 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
       rdv(1, vb);
       mm(0, va);
       __builtin_amdgcn_sched_barrier(0);
-      rdv(2, va);
       mm(1, vb);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(2, va);
       __builtin_amdgcn_sched_barrier(0);
       slab_store(s + 1, xr_next);
       __syncthreads();
@@ -291,43 +275,58 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
   {
     // h1 halo: slot 0 (frame -1); frames >= T are written as zeros by the epilogue below, slot 32 NT + 1 here
     if (tid < 16) *(uint4*)(h1S + (tid < 8 ? 0 : (nslots - 1) * 128) + (tid & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
-    const int nmine = (NT - wave + 3) / 4;
+    const int nmine = (NT - wave + NW - 1) / NW;
 #pragma unroll
     for (int j = 0; j < MAXT1; ++j)
-      if (j < nmine) store_split<32>(acc1[j], a.b1, 0, h1S, TW * (wave + 4 * j) + col, T, h);
+      if (j < nmine) store_split<32>(acc1[j], a.b1, 0, h1S, TW * (wave + NW * j) + col, T, h);
+  }
+  // hi / lo weight fragments of layer 2 (this wave's 32 output channels): requested in front of the barrier
+  uint4 w2h[6], w2l[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    w2h[i] = a.w2[((size_t)((wave & 1) * 6 + i) * 2) * 64 + lane];
+    w2l[i] = a.w2[((size_t)((wave & 1) * 6 + i) * 2 + 1) * 64 + lane];
   }
   __syncthreads();
 
   // ------------------------------------------------------------------------------------------------ layer 2: 32 -> 64
   {
-    const int m = wave & 1, par = wave >> 1;
+    const int m = wave & 1, par = wave >> 1;                 // 32 of the 64 channels; tiles par, par + 4, par + 8
+    constexpr int ST = NW / 2;
     if (tid < 32) *(uint4*)(h2S + (tid < 16 ? 0 : (nslots - 1) * 256) + (tid & 15) * 16) = make_uint4(0u, 0u, 0u, 0u);
     // tile i's bias + ReLU + split + store rides on tile i + 1's steps (one 4-channel group per step)
     f32x16_t accA, accB;
     int tile = par;
     if (tile < NT) {
       split_gemm<32>(w2h, w2l, h1S, TW * tile, col, h, accA, [](int) {});
-      for (tile += 2; tile + 2 < NT; tile += 4) {
+      for (tile += ST; tile + ST < NT; tile += 2 * ST) {
         split_gemm<32>(w2h, w2l, h1S, TW * tile, col, h, accB,
-                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accA, a.b2, 32 * m, h2S, TW * (tile - 2) + col, T, h, i - 1); });
-        split_gemm<32>(w2h, w2l, h1S, TW * (tile + 2), col, h, accA,
+                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accA, a.b2, 32 * m, h2S, TW * (tile - ST) + col, T, h, i - 1); });
+        split_gemm<32>(w2h, w2l, h1S, TW * (tile + ST), col, h, accA,
                        [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accB, a.b2, 32 * m, h2S, TW * tile + col, T, h, i - 1); });
       }
       if (tile < NT) {
         split_gemm<32>(w2h, w2l, h1S, TW * tile, col, h, accB,
-                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accA, a.b2, 32 * m, h2S, TW * (tile - 2) + col, T, h, i - 1); });
+                       [&](int i) { if (i >= 1 && i < 5) store_split_g<64>(accA, a.b2, 32 * m, h2S, TW * (tile - ST) + col, T, h, i - 1); });
         store_split<64>(accB, a.b2, 32 * m, h2S, TW * tile + col, T, h);
       } else {
-        store_split<64>(accA, a.b2, 32 * m, h2S, TW * (tile - 2) + col, T, h);
+        store_split<64>(accA, a.b2, 32 * m, h2S, TW * (tile - ST) + col, T, h);
       }
     }
+  }
+  // layer 3's fragments (32 of the 128 channels per wave; two waves share a channel tile and split its frame tiles)
+  uint4 w3h[12], w3l[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    w3h[i] = a.w3[((size_t)((wave & 3) * 12 + i) * 2) * 64 + lane];
+    w3l[i] = a.w3[((size_t)((wave & 3) * 12 + i) * 2 + 1) * 64 + lane];
   }
   __syncthreads();
   if (stamp) a.stamps[8 * b + 2] = __builtin_amdgcn_s_memtime();
 
   // ------------------------------------------------------------------------------------------------ layer 3: 64 -> 128, frame mean, classifier
   {
-    const int m = wave;
+    const int m = wave & 3, par = wave >> 2;                 // tiles par, par + 2, ...
     float bias[16], sum[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -340,19 +339,21 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
       for (int r = r0; r < r0 + 2; ++r) sum[r] += inside ? fmaxf(v[r] + bias[r], 0.f) : 0.f;
     };
     f32x16_t accA, accB;
-    split_gemm<64>(w3h, w3l, h2S, 0, col, h, accA, [](int) {});
-    int tile = 1;
-    for (; tile + 1 < NT; tile += 2) {
-      split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accB, [&](int i) { if (i >= 2 && i < 10) add_regs(accA, tile - 1, 2 * (i - 2)); });
-      split_gemm<64>(w3h, w3l, h2S, TW * (tile + 1), col, h, accA, [&](int i) { if (i >= 2 && i < 10) add_regs(accB, tile, 2 * (i - 2)); });
-    }
+    int tile = par;
     if (tile < NT) {
-      split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accB, [&](int i) { if (i >= 2 && i < 10) add_regs(accA, tile - 1, 2 * (i - 2)); });
+      split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accA, [](int) {});
+      for (tile += 2; tile + 2 < NT; tile += 4) {
+        split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accB, [&](int i) { if (i >= 2 && i < 10) add_regs(accA, tile - 2, 2 * (i - 2)); });
+        split_gemm<64>(w3h, w3l, h2S, TW * (tile + 2), col, h, accA, [&](int i) { if (i >= 2 && i < 10) add_regs(accB, tile, 2 * (i - 2)); });
+      }
+      if (tile < NT) {
+        split_gemm<64>(w3h, w3l, h2S, TW * tile, col, h, accB, [&](int i) { if (i >= 2 && i < 10) add_regs(accA, tile - 2, 2 * (i - 2)); });
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) add_regs(accB, tile, r);
-    } else {
+        for (int r = 0; r < 16; r += 2) add_regs(accB, tile, r);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) add_regs(accA, tile - 1, r);
+        for (int r = 0; r < 16; r += 2) add_regs(accA, tile - 2, r);
+      }
     }
     float part = 0.f;
     const float inv_t = 1.0f / (float)T;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
   }
   __syncthreads();
   if (stamp) { a.stamps[8 * b + 3] = __builtin_amdgcn_s_memtime(); a.stamps[8 * b + 6] = __builtin_amdgcn_s_memrealtime(); }
-  if (tid == 0) a.logits[b] = ((red[0] + red[1]) + (red[2] + red[3])) + a.cb[0];
+  if (tid == 0) a.logits[b] = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) + a.cb[0];
 }
 
 static void cnn1d_x3_layout(int T, int F, int* offB, int* total, int* slab_floats) {
@@ -382,7 +383,8 @@ static void cnn1d_x3_layout(int T, int F, int* offB, int* total, int* slab_float
 }
 // x must be the contiguous [B][F][T] storage (element (b, t, f) at b F T + f T + t), 16-byte aligned
 bool cnn1d_fused_x3_supports(const void* x, int64_t sb, int64_t st, int64_t sf, int T, int F) {
-  if (T < 3 || (T + 31) / 32 > 4 * c1x::MAXT1 || F < 1 || (F & 3)) return false;
+  // (a slab of 16 channels = 4 T float4 must fit the 3 x 512 loads of a trip: T <= 384)
+  if (T < 3 || T > 384 || (T + 31) / 32 > c1x::NW * c1x::MAXT1 || F < 1 || (F & 3)) return false;
   if (st != 1 || sf != T || sb != (int64_t)F * T || ((uintptr_t)x & 15)) return false;
   int offB, total, sl;
   cnn1d_x3_layout(T, F, &offB, &total, &sl);
@@ -399,7 +401,7 @@ hipError_t launch_cnn1d_fused_x3(const float* x, const void* w1, const float* b1
   cnn1d_x3_layout(T, F, &a.offB, &total, &a.slab_floats);
   hipError_t e = hipFuncSetAttribute((const void*)cnn1d_fused_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cnn1d_fused_x3_kernel, dim3(B), dim3(256), total, s, a);
+  hipLaunchKernelGGL(cnn1d_fused_x3_kernel, dim3(B), dim3(c1x::NTH), total, s, a);
   return hipGetLastError();
 }
 
