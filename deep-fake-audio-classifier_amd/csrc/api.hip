@@ -218,6 +218,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "cae_enc_dma") == 0) { ctx->cae_enc_dma = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_dec_fused") == 0) { ctx->cae_dec_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value < 0 ? 0 : (value > 2 ? 1 : value); return DFA_OK; }
   if (strcmp(name, "block3_m16") == 0) { ctx->block3_m16 = value ? 1 : 0; return DFA_OK; }
@@ -630,9 +631,10 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
     ScopedSlot ts(ctx, 9 + l);
     ConvArgs a{};
     a.in = e[l]; a.wpack = m.enc[l].wpack; a.bias = m.enc[l].bias; a.out = e[l + 1];
-    a.B = B; a.H = pl.H[l + 1]; a.W = pl.W[l + 1]; a.COUT = ecout[l]; a.relu = 1;
-    hipError_t err = (l == 0) ? launch_cae_enc2(prec, a, s, ctx->lds_pipe) : (l == 1) ? launch_cae_enc3(prec, a, s, ctx->lds_pipe)
-                                                                        : launch_cae_enc4(prec, a, (float*)(ws + pl.raw_off), s);
+    a.B = B; a.H = pl.H[l + 1]; a.W = pl.W[l + 1]; a.COUT = ecout[l]; a.relu = 1; a.zero_page = ctx->zero_page;
+    const int dma = ctx->cae_enc_dma;
+    hipError_t err = (l == 0) ? launch_cae_enc2(prec, a, s, ctx->lds_pipe, dma) : (l == 1) ? launch_cae_enc3(prec, a, s, ctx->lds_pipe, dma)
+                                                                             : launch_cae_enc4(prec, a, (float*)(ws + pl.raw_off), s, dma);
     DFA_HIP_CHECK(ctx, err);
   }
   if (latent) DFA_HIP_CHECK(ctx, launch_cae_latent_export(e[3], prec, latent, B, pl.H[4] * pl.W[4], 256, s));

@@ -8,14 +8,17 @@
 
 namespace dfa {
 
-hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe) {
+// dma = 1 (bf16): the input ring is staged by LDS-DMA (global_load_lds), as the CNN2D blocks do; 0 = through registers
+hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe, int dma) {
+  if (prec == DFA_PREC_BF16 && dma && pipe) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_2X2, 2, false, true>(a, s);
   if (prec == DFA_PREC_BF16)
     return pipe ? launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_2X2, 2>(a, s)
                 : launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_POOL_2X2, 2, false, false, false, 0>(a, s);
   return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_POOL_2X2, 1>(a, s);
 }
 
-hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe) {
+hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe, int dma) {
+  if (prec == DFA_PREC_BF16 && dma && pipe) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_POOL_2X2, 2, false, true>(a, s);
   if (prec == DFA_PREC_BF16)
     return pipe ? launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_POOL_2X2, 2>(a, s)
                 : launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_POOL_2X2, 2, false, false, false, 0>(a, s);
@@ -23,7 +26,8 @@ hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe)
 }
 
 // a.wpack: bf16 -> one [256/32][9][8][64] image; fp32 -> two consecutive [256/32][9][8][64] images (Cin halves)
-hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
+hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s, int dma) {
+  if (prec == DFA_PREC_BF16 && dma) return launch_conv3x3<bf16_t, 128, 4, 1, 1, 1, EPI_POOL_2X2, 1, false, true>(a, s);
   if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 128, 4, 1, 1, 1, EPI_POOL_2X2, 1>(a, s);
   ConvArgs p1 = a;
   p1.in_pix_bytes = 128 * 4;

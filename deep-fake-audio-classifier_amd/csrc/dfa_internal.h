@@ -103,6 +103,7 @@ struct dfa_ctx {
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
+  int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel when T <= 384: 1 = split-bf16 kernel (cnn1d_fused_x3.hip) for the reference's
                                // storage layout, the exact-fp32 one (cnn1d_fused.hip) otherwise; 2 = always the exact-fp32 one; 0 = the three-launch path
@@ -338,9 +339,9 @@ hipError_t launch_conv12_fused(const void* x, int x_dtype, int64_t sb, int64_t s
 hipError_t launch_cnn2d_block2(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 hipError_t launch_cnn2d_block3(int prec, const ConvArgs& a, hipStream_t s, int dma = -1, int pipe = 1);
 struct ConvTArgs;
-hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1);
-hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1);
-hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1, int dma = 0);
+hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1, int dma = 0);
+hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s, int dma = 0);
 hipError_t launch_cae_dec(int prec, int cin, const ConvTArgs& a, hipStream_t s);
 
 }  // namespace dfa
