@@ -218,6 +218,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv1_bwd_fused") == 0) { ctx->conv1_bwd_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "dgrad_m16") == 0) { ctx->dgrad_m16 = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "conv1_mfma") == 0) { ctx->conv1_mfma = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "cae_enc1_mfma") == 0) { ctx->cae_enc1_mfma = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_enc_dma") == 0) { ctx->cae_enc_dma = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_dec_fused") == 0) { ctx->cae_dec_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value < 0 ? 0 : (value > 2 ? 1 : value); return DFA_OK; }
@@ -566,6 +567,10 @@ int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
   for (int l = 0; l < 3; ++l) { dw[l] = off; off = align_up(off + (size_t)dcout[l] * dcin[l] * 4 * 4, 256); }
   const size_t cst_off = off;
   off = align_up(off + 16 * sizeof(float), 256);
+  const size_t c1p_off = off;
+  off = align_up(off + 6 * 64 * 16 + 256, 256);
+  const size_t d4p_off = off;
+  off = align_up(off + 4 * 64 * 16, 256);
   if (!m.packed) DFA_HIP_CHECK(ctx, hipMalloc(&m.packed, off));
   char* base = (char*)m.packed;
   m.w1 = (float*)base;
@@ -596,6 +601,11 @@ int dfa_cae_prepare(dfa_ctx* ctx, int precision) {
     DFA_HIP_CHECK(ctx, launch_fold_pack_convt2x2(q[0], q[1], q[2], q[3], q[4], q[5], dcin[l], dcout[l], precision, m.dec[l].wpack, m.dec[l].bias, s));
   }
   m.opad_cst = (float*)(base + cst_off);
+  m.c1pack = (uint4*)(base + c1p_off);
+  m.c1bias = (float*)(base + c1p_off + 6 * 64 * 16);
+  DFA_HIP_CHECK(ctx, launch_pack_cae_enc1_mfma(m.w1, m.b1, m.c1pack, m.c1bias, s));
+  m.dec4pack = (uint4*)(base + d4p_off);
+  DFA_HIP_CHECK(ctx, launch_pack_cae_dec4(p[42], m.dec4pack, s));
   if (precision == DFA_PREC_BF16)   // the constants the fused decoder uses for the columns grown from block 2's output_padding column
     DFA_HIP_CHECK(ctx, launch_cae_opad_consts(m.dec[1].bias, m.dec[2].wpack, m.dec[2].bias, p[42], p[43], m.opad_cst, s));
   m.prepared_prec = precision;
@@ -625,7 +635,10 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
   void* d[3] = {ws + pl.d_off[0], ws + pl.d_off[1], ws + pl.d_off[2]};
   hipStream_t s = ctx->stream;
   { ScopedSlot ts(ctx, 8);
-    DFA_HIP_CHECK(ctx, launch_cae_enc1(x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, m.w1, m.b1, e[0], prec, B, T, F, s)); }
+    if (prec == DFA_PREC_BF16 && ctx->cae_enc1_mfma && F <= 1022)    // block 1 on the matrix cores (hi + lo bf16 operands)
+      DFA_HIP_CHECK(ctx, launch_cae_enc1_mfma(x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, m.c1pack, m.c1bias, e[0], B, T, F, s));
+    else
+      DFA_HIP_CHECK(ctx, launch_cae_enc1(x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, m.w1, m.b1, e[0], prec, B, T, F, s)); }
   const int ecout[3] = {64, 128, 256};
   for (int l = 0; l < 3; ++l) {
     ScopedSlot ts(ctx, 9 + l);
@@ -643,7 +656,7 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
       ScopedSlot ts(ctx, 12);
       float* partial = (float*)(ws + pl.part_off);
       DFA_HIP_CHECK(ctx, launch_cae_dec_fused(e[3], m.dec[0].wpack, m.dec[0].bias, m.dec[1].wpack, m.dec[1].bias, m.dec[2].wpack, m.dec[2].bias,
-                                              m.p[42], m.p[43], m.opad_cst, x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, recon, partial,
+                                              m.p[42], m.p[43], m.dec4pack, m.opad_cst, x, x_dtype, stride_b, stride_t, stride_f, mu, sigma, recon, partial,
                                               B, pl.H[4], pl.W[4], T, F, s, ctx->clock_probe ? ctx->clock_buf : nullptr));
       if (mse) DFA_HIP_CHECK(ctx, launch_cae_mse_finalize(partial, cae_dec_fused_tiles(pl.H[4], pl.W[4]), 1.0f / ((float)T * (float)F), mse, B, s));
     }

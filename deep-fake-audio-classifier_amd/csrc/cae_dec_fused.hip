@@ -29,6 +29,7 @@ struct CaeDecFusedArgs {
   const uint4 *wp1, *wp2, *wp3;    // [4*COUT/32][CIN/16][64] x 16 bytes (launch_fold_pack_convt2x2, bf16)
   const float *b1, *b2, *b3;       // folded biases [128], [64], [32]
   const float *w4, *b4;            // ConvTranspose2d(32 -> 1) weight [32][4], bias [1] (raw, fp32)
+  const uint4* w4pack;             // the same weights as MFMA A operands [2 k-steps][hi, lo][64] (pack_cae_dec4_kernel)
   const float* cst;                // [16] reconstruction constants of the output_padding columns: cst[(t & 3) * 4 + (f - 16 W4)]
   const void* x;
   int x_bf16;
@@ -165,6 +166,9 @@ __global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a
     float b3v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) b3v[r] = a.b3[(r & 3) + 8 * (r >> 2) + 4 * h];
+    uint4 w4f[4];                                   // [k-step 0: hi, lo][k-step 1: hi, lo]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4f[i] = a.w4pack[i * 64 + lane];
     const float b4 = a.b4[0];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -186,16 +190,27 @@ __global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) acc = Mma<bf16_t>::run(wa[mt][kg], xv[kg], acc);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        // d3 = bf16(relu(acc + bias)) never leaves the registers: converted pairwise it IS the B operand of the 32 -> 1 layer
+        // (k-step s = registers 8 s .. 8 s + 7; the packed W4 image follows the same permuted channel order), W4 = hi + lo bf16:
+        // four MFMAs instead of 64 FMAs + 16 LDS reads + 4 cross-half exchanges per lane
+        uint4 dfr[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = bf16_to_float(float_to_bf16(relu1(acc[r] + b3v[r], rlim)));   // d3 is a bf16 tensor in this mode
-          const float4 w = w4S[(r & 3) + 8 * (r >> 2) + 4 * h];
-          s0 = fmaf(v, w.x, s0); s1 = fmaf(v, w.y, s1); s2 = fmaf(v, w.z, s2); s3 = fmaf(v, w.w, s3);
+        for (int s = 0; s < 2; ++s) {
+          unsigned pk[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            pk[p] = pack_bf16x2(relu1(acc[8 * s + 2 * p] + b3v[8 * s + 2 * p], rlim), relu1(acc[8 * s + 2 * p + 1] + b3v[8 * s + 2 * p + 1], rlim));
+          dfr[s] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
-        s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); s3 += __shfl_xor(s3, 32, 64);
-        // half h finishes output row a4 = h of the pixel's 2 x 2 patch
-        const float r0 = (h ? s2 : s0) + b4, r1 = (h ? s3 : s1) + b4;
+        f32x16_t y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = 0.f;
+        y = Mma<bf16_t>::run(w4f[1], dfr[0], y);
+        y = Mma<bf16_t>::run(w4f[3], dfr[1], y);
+        y = Mma<bf16_t>::run(w4f[0], dfr[0], y);
+        y = Mma<bf16_t>::run(w4f[2], dfr[1], y);
+        // rows 4 h, 4 h + 1 of y = outputs (a4 = h, c4 = 0, 1) of this lane's pixel: registers 0, 1
+        const float r0 = y[0] + b4, r1 = y[1] + b4;
         const int t = tq + 2 * (mt >> 1) + h, f = fq + 2 * (mt & 1);
         if (valid) {
           const float d0 = r0 - cdf_ldx(a, b, t, f), d1 = r1 - cdf_ldx(a, b, t, f + 1);
@@ -260,6 +275,30 @@ __global__ __launch_bounds__(128) void cae_opad_consts_kernel(const float* __res
   }
 }
 
+// W4 [32 ch][4] as the A operand of v_mfma_f32_32x32x16_bf16 for "accumulator tile as the next operand": rows 0, 1 = outputs
+// q4 = 0, 1 and rows 4, 5 = outputs 2, 3 (so that lane half h finds its patch row a4 = h in accumulator registers 0, 1), zero
+// elsewhere; k-step s, lane half hh, element j <-> channel 16 s + 8 (j >> 2) + 4 hh + (j & 3) -- the order in which registers
+// 8 s .. 8 s + 7 of a 32 x 32 accumulator hold their rows (cdna_hip_programming.md section 3).  pack[2 s + part][lane], part 0 = hi.
+__global__ void pack_cae_dec4_kernel(const float* __restrict__ w4, uint4* __restrict__ pack) {
+  const int i = threadIdx.x;                     // 256 = [s][part][lane]
+  const int lane = i & 63, part = (i >> 6) & 1, s = i >> 7;
+  const int row = lane & 31, hh = lane >> 5;
+  const int q4 = row == 0 ? 0 : row == 1 ? 1 : row == 4 ? 2 : row == 5 ? 3 : -1;
+  bf16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+    const float w = q4 >= 0 ? w4[c * 4 + q4] : 0.f;
+    const bf16_t hi = float_to_bf16(w);
+    v[j] = part ? float_to_bf16(w - bf16_to_float(hi)) : hi;
+  }
+  pack[i] = *reinterpret_cast<const uint4*>(v);
+}
+hipError_t launch_pack_cae_dec4(const float* w4, uint4* pack, hipStream_t s) {
+  hipLaunchKernelGGL(pack_cae_dec4_kernel, dim3(1), dim3(256), 0, s, w4, pack);
+  return hipGetLastError();
+}
+
 hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float* b3, const float* w4, const float* b4, float* cst,
                                   hipStream_t s) {
   hipLaunchKernelGGL(cae_opad_consts_kernel, dim3(1), dim3(128), 0, s, b2, wp3, b3, w4, b4, cst);
@@ -269,10 +308,11 @@ hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float
 int cae_dec_fused_tiles(int H4, int W4) { return (H4 * W4 + cdf::NP - 1) / cdf::NP; }
 
 hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* b1, const uint4* wp2, const float* b2, const uint4* wp3,
-                                const float* b3, const float* w4, const float* b4, const float* cst, const void* x, int x_dtype,
-                                int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon, float* partial,
-                                int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps) {
+                                const float* b3, const float* w4, const float* b4, const uint4* w4pack, const float* cst, const void* x,
+                                int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon,
+                                float* partial, int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps) {
   CaeDecFusedArgs a{};
+  a.w4pack = w4pack;
   a.stamps = stamps;
   a.lat = (const bf16_t*)lat; a.wp1 = wp1; a.wp2 = wp2; a.wp3 = wp3; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.w4 = w4; a.b4 = b4; a.cst = cst;
   a.x = x; a.x_bf16 = x_dtype == DFA_DTYPE_BF16 ? 1 : 0; a.sb = sb; a.st = st; a.sf = sf; a.mu = mu; a.sigma = sigma;

@@ -81,6 +81,9 @@ struct CaeState {
   float *w1 = nullptr, *b1 = nullptr;
   PackedConv enc[3];   // encoder blocks 2-4
   PackedConv dec[3];   // decoder blocks 1-3 (ConvTranspose2d images)
+  uint4* c1pack = nullptr;     // block-1 MFMA A operands [6][64]: three bf16 terms of the folded weights, even / odd row (cae_enc1_mfma.hip)
+  float* c1bias = nullptr;     // [32] 0.5 * folded bias
+  uint4* dec4pack = nullptr;   // decoder block 4 as MFMA A operands [4][64] (cae_dec_fused.hip)
   float* opad_cst = nullptr;   // [16] reconstruction constants of the output_padding columns (cae_dec_fused.hip)
   // train mode (cae_train_api.hip): raw forward images, data-gradient images, raw ConvTranspose2d images
   void* train_packed = nullptr;
@@ -103,6 +106,7 @@ struct dfa_ctx {
   int conv1_bwd_fused = 1;     // CNN2D training: block-1 backward as ONE pass over da1 (train_conv1.hip BWD_FUSED); 0 = reduce pass + weight-gradient pass
   int conv1_mfma = 1;          // bf16 training, bf16 features, no folded augmentation: block-1 passes on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
+  int cae_enc1_mfma = 1;       // auto-encoder eval forward, bf16 mode: block 1 on the matrix cores (cae_enc1_mfma.hip); 0 = the vector-ALU kernel
   int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel when T <= 384: 1 = split-bf16 kernel (cnn1d_fused_x3.hip) for the reference's
@@ -192,14 +196,19 @@ hipError_t launch_emb_reduce(const float* parts, int nparts, size_t stride, size
 // conv1d.hip
 hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, const float* beta, const float* mean,
                               const float* var, float* wf, float* bf, int cin, int cout, hipStream_t s);
+// cae_enc1_mfma.hip: auto-encoder block 1 (conv 1 -> 32 + ReLU + 2 x 2 pool) on the matrix cores, bf16 mode
+hipError_t launch_cae_enc1_mfma(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma,
+                                const uint4* c1pack, const float* c1bias, void* out, int B, int T, int F, hipStream_t s);
+hipError_t launch_pack_cae_enc1_mfma(const float* w1, const float* b1, uint4* pack, float* bias, hipStream_t s);
 // cae_dec_fused.hip: the auto-encoder's decoder + per-sample squared error as one kernel (bf16 mode)
 int cae_dec_fused_tiles(int H4, int W4);
 hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float* b3, const float* w4, const float* b4, float* cst,
                                   hipStream_t s);
 hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* b1, const uint4* wp2, const float* b2, const uint4* wp3,
-                                const float* b3, const float* w4, const float* b4, const float* cst, const void* x, int x_dtype,
-                                int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon, float* partial,
-                                int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps = nullptr);
+                                const float* b3, const float* w4, const float* b4, const uint4* w4pack, const float* cst, const void* x,
+                                int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon,
+                                float* partial, int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps = nullptr);
+hipError_t launch_pack_cae_dec4(const float* w4, uint4* pack, hipStream_t s);
 hipError_t launch_cae_mse_finalize(const float* partial, int nblk, float inv_n, float* mse, int B, hipStream_t s);
 // cnn1d_fused.hip: the whole CNN1D eval forward as one kernel (fp32 matrix cores, activations in LDS)
 int cnn1d_fused_ncp_pad(int cin, int layer);

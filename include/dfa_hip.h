@@ -88,6 +88,10 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   earlier 4-wave kernel (process-wide)
  *   "train_conv_variant" 2 (default) = pipelined two-wave bf16 training convolutions where they fit, 0 = their
  *                   compiler-scheduled twins, 1 = the one-wave-per-SIMD instantiations (process-wide)
+ *   "cae_enc1_mfma" 1 (default) = auto-encoder eval forward in bf16 mode: block 1 (conv 1 -> 32 + ReLU + 2 x 2 pool) on the matrix
+ *                   cores with hi + lo bf16 operands; 0 = the vector-ALU kernel
+ *   "cae_enc_dma"   1 (default) = auto-encoder eval forward in bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA;
+ *                   0 = through registers (bit-identical)
  *   "cae_dec_fused" 1 (default) = auto-encoder eval forward in bf16 mode: the four decoder blocks, the zero time padding and the
  *                   per-sample squared error run as ONE kernel with the intermediates in LDS / registers; 0 = four launches
  *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel for T <= 384 (all three Conv1d layers on the matrix cores with the

@@ -192,3 +192,40 @@ def test_cae_fused_decoder_is_one_launch(golden):
     counts = [ctx.timing_read(s)[1] for s in range(8, 16)]
     ctx.timing_reset()
     assert counts == [1, 1, 1, 1, 1, 0, 0, 0], counts
+
+
+@pytest.mark.parametrize("B,T,F,xdt,view,zs", [(3, 321, 180, torch.float32, True, True), (2, 321, 180, torch.bfloat16, True, False),
+                                                (4, 70, 180, torch.float32, False, True), (2, 64, 36, torch.bfloat16, False, False),
+                                                (1, 16, 20, torch.float32, True, False)])
+def test_cae_block1_on_matrix_cores_matches_vector_kernel(golden, B, T, F, xdt, view, zs):
+    """Round 3: encoder block 1 (conv 1 -> 32 + ReLU + 2 x 2 pool, z-score fused) on the matrix cores with hi + lo bf16 operands
+    (csrc/cae_enc1_mfma.hip) against the fp32 vector-ALU kernel it replaces in bf16 mode: the stored bf16 e1 may differ by a
+    rounding on a few elements (products carried to 2^-17), so latent / reconstruction / score are compared at bf16 storage noise,
+    and the reconstruction with the rounding-faithful oracle at the existing 4e-3."""
+    from dfa_amd import _lib
+    from oracle import torch_ref as R
+    sd, _ = golden("cae_eval")
+    model = _model(sd, precision="bf16")
+    gen = torch.Generator().manual_seed(7 * B + T + F)
+    stored = torch.randn(B, F, T, generator=gen) if view else torch.randn(B, T, F, generator=gen)
+    x = stored.to("cuda", xdt)
+    x = x.transpose(1, 2) if view else x
+    mean, std = (0.1 * torch.randn(F, generator=gen), 0.5 + torch.rand(F, generator=gen)) if zs else (None, None)
+    ctx = _lib.Context.get(x.device)
+    xin = x if not zs else ((x.float() - mean.cuda()) / std.cuda())
+    got_r, got_l = model(xin)
+    got_s = model.score(x, mean, std) if zs else model.score(x)
+    ctx.set_option("cae_enc1_mfma", 0)
+    try:
+        ref_r, ref_l = model(xin)
+        ref_s = model.score(x, mean, std) if zs else model.score(x)
+    finally:
+        ctx.set_option("cae_enc1_mfma", 1)
+    scale = max(1.0, float(ref_r.abs().max()))
+    assert float((got_r - ref_r).abs().max()) <= 2e-3 * scale, float((got_r - ref_r).abs().max())
+    assert float((got_l - ref_l).abs().max()) <= 2e-2 * max(1.0, float(ref_l.abs().max()))
+    np.testing.assert_allclose(got_s.cpu().numpy(), ref_s.cpu().numpy(), rtol=1e-3)
+    want_r, _ = R.cae_forward_emulated(sd, xin.float().cpu(), "bf16")
+    assert float((got_r.cpu() - want_r).abs().max()) / max(1.0, float(want_r.abs().max())) < 4e-3
+    print(f"[cae enc1 mfma {B},{T},{F}] max recon diff vs vector kernel {float((got_r - ref_r).abs().max()):.2e}, "
+          f"vs emulated oracle {float((got_r.cpu() - want_r).abs().max()):.2e}")
