@@ -651,7 +651,7 @@ int dfa_cae_forward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int 
     DFA_HIP_CHECK(ctx, err);
   }
   if (latent) DFA_HIP_CHECK(ctx, launch_cae_latent_export(e[3], prec, latent, B, pl.H[4] * pl.W[4], 256, s));
-  if (prec == DFA_PREC_BF16 && ctx->cae_dec_fused) {   // decoder + squared error in one kernel: d1, d2, d3 never leave the CU (slot 12)
+  if (prec == DFA_PREC_BF16 && ctx->cae_dec_fused && cae_dec_fused_supports(T, F, stride_t, stride_f)) {   // decoder + squared error in one kernel: d1, d2, d3 never leave the CU (slot 12)
     if (recon || mse) {
       ScopedSlot ts(ctx, 12);
       float* partial = (float*)(ws + pl.part_off);

@@ -42,10 +42,14 @@ struct CaeDecFusedArgs {
 };
 
 namespace cdf {
-constexpr int NP = 32;                       // latent pixels per workgroup
-constexpr int LAT_B = NP * 512, D1_B = 4 * NP * 256, D2_B = 16 * NP * 128;
-constexpr int W4_OFF = LAT_B + D1_B + D2_B;  // [32] float4
-constexpr int RED_OFF = W4_OFF + 512;        // [8] float
+#ifndef DFA_CDF_NP
+#define DFA_CDF_NP 64
+#endif
+constexpr int NP = DFA_CDF_NP;               // latent pixels per workgroup (32 or 64)
+constexpr int LAT_B = NP * 512, D1_B = 4 * NP * 256;
+constexpr int B2_OFF = LAT_B + D1_B;         // [64] float: block 2's folded bias (read per unit; global loads there would serialise)
+constexpr int W3_OFF = B2_OFF + 256;         // [4 q3][4 k-steps][64 lanes] x 16 B: block 3's fragments in the permuted channel order
+constexpr int RED_OFF = W3_OFF + 16384;      // [8] float
 constexpr int LDS_BYTES = RED_OFF + 64;
 }  // namespace cdf
 
@@ -56,14 +60,22 @@ __device__ __forceinline__ float cdf_ldx(const CaeDecFusedArgs& a, int b, int t,
   return v;
 }
 
-__global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a) {
+// raw x element (no branches: XBF is a template parameter, so eight of these issue back to back)
+template <bool XBF>
+__device__ __forceinline__ float cdf_ldraw(const void* xu, unsigned off) {   // xu = the utterance's base (uniform), off in elements
+  if constexpr (XBF) return bf16_to_float(((const bf16_t*)xu)[off]);
+  else return ((const float*)xu)[off];
+}
+
+template <bool XBF, bool NORM>
+__global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a) {
   using namespace cdf;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const latS = smem;
   char* const d1S = smem + LAT_B;
-  char* const d2S = smem + LAT_B + D1_B;
-  float4* const w4S = (float4*)(smem + W4_OFF);
   float* const red = (float*)(smem + RED_OFF);
+  float* const b2S = (float*)(smem + B2_OFF);
+  const uint4* const w3S = (const uint4*)(smem + W3_OFF);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, h = lane >> 5;
@@ -74,17 +86,50 @@ __global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a
   const bool stamp = a.stamps != nullptr && tid == 0 && sid < 128;
   if (stamp) { a.stamps[8 * sid] = __builtin_amdgcn_s_memtime(); a.stamps[8 * sid + 6] = __builtin_amdgcn_s_memrealtime(); }
 
-  // ---- stage the latent tile (32 pixels x 512 B, contiguous) with the chunk swizzle of the fragment reads; W4 -> LDS
+  uint4 wa[16], wn[16];            // phase A's weight fragments (m-tiles 2 wave, 2 wave + 1), requested inside the staging block
+  // ---- stage the latent tile (NP pixels x 512 B, contiguous) with the chunk swizzle of the fragment reads; b2 and W3 -> LDS.
+  //      All loads first and unconditional (clamped address, masked value): a load under a branch costs a full wait each.
   {
     const char* src = (const char*)(a.lat + ((size_t)b * npx + g0) * 256);
+    const int nvalid = (npx - g0) * 32;              // 16-byte chunks of this tile that exist
+    uint4 v[NP / 16];
+#pragma unroll
+    for (int it = 0; it < NP / 16; ++it) {
+      const int g = tid + 512 * it;
+      v[it] = *(const uint4*)(src + (size_t)(g < nvalid ? g : 0) * 16);
+    }
+    // W3 fragment of lane (i, hh) in the order the d2 accumulators present their channels: elements 0-3 = the standard image's
+    // lane (i, 0) elements 4 hh .. 4 hh + 3, elements 4-7 = lane (i, 1)'s
+    const uint2* w3h = reinterpret_cast<const uint2*>(a.wp3);
+    uint2 e[2][2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int g = tid + 512 * it, p = g >> 5, c = g & 31;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (g0 + p < npx) v = *(const uint4*)(src + (size_t)g * 16);
-      *(uint4*)(latS + p * 512 + ((c ^ (p & 15)) << 4)) = v;
+      const int f = (tid >> 6) + 8 * it;
+      e[it][0] = w3h[((size_t)f * 64 + col) * 2 + h];
+      e[it][1] = w3h[((size_t)f * 64 + 32 + col) * 2 + h];
     }
-    if (tid < 32) w4S[tid] = make_float4(a.w4[4 * tid], a.w4[4 * tid + 1], a.w4[4 * tid + 2], a.w4[4 * tid + 3]);
+    const float b2v = a.b2[tid & 63];
+    // phase A's fragments go out behind the tile's loads (memory returns in order: the LDS writes below wait for the tile only,
+    // the 32 fragment loads stay in flight across the barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const uint4* wp = a.wp1 + lane;
+#pragma unroll
+      for (int kg = 0; kg < 16; ++kg) wa[kg] = wp[(size_t)((2 * wave) * 16 + kg) * 64];
+#pragma unroll
+      for (int kg = 0; kg < 16; ++kg) wn[kg] = wp[(size_t)((2 * wave + 1) * 16 + kg) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NP / 16; ++it) {
+      const int g = tid + 512 * it, p = g >> 5, c = g & 31;
+      const bool ok = g < nvalid;
+      *(uint4*)(latS + p * 512 + ((c ^ (p & 15)) << 4)) = make_uint4(ok ? v[it].x : 0u, ok ? v[it].y : 0u, ok ? v[it].z : 0u, ok ? v[it].w : 0u);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      *(uint4*)(smem + W3_OFF + ((((tid >> 6) + 8 * it) * 64 + lane) << 4)) = make_uint4(e[it][0].x, e[it][0].y, e[it][1].x, e[it][1].y);
+    if (tid < 64) b2S[tid] = b2v;
   }
   __syncthreads();
   if (stamp) a.stamps[8 * sid + 1] = __builtin_amdgcn_s_memtime();
@@ -101,106 +146,130 @@ __global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a
     }
   };
 
+  const int q2 = wave & 3;
+  uint4 w2[2][8];                  // phases B + C: block 2's m-tiles 2 q2, 2 q2 + 1 (requested inside phase A, see there)
   // ---- phase A: d1 = relu(W1 . lat): wave owns m-tiles 2 wave, 2 wave + 1 (n = q1 * 128 + co)
   {
-    uint4 wa[16], wn[16];
-    const uint4* wp = a.wp1 + lane;
-#pragma unroll
-    for (int kg = 0; kg < 16; ++kg) wa[kg] = wp[(size_t)((2 * wave) * 16 + kg) * 64];
-#pragma unroll
-    for (int kg = 0; kg < 16; ++kg) wn[kg] = wp[(size_t)((2 * wave + 1) * 16 + kg) * 64];
-    const char* xb = latS + col * 512;
     const int sw = col & 15;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int mt = 2 * wave + mi;
-      f32x16_t acc;
+      f32x16_t acc[NP / 32];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int n = 0; n < NP / 32; ++n)
 #pragma unroll
-      for (int kg = 0; kg < 16; ++kg) {
-        const uint4 xv = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
-        acc = Mma<bf16_t>::run(mi == 0 ? wa[kg] : wn[kg], xv, acc);
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < 16; ++kg)
+#pragma unroll
+        for (int n = 0; n < NP / 32; ++n) {
+          const uint4 xv = *(const uint4*)(latS + (32 * n + col) * 512 + (((2 * kg + h) ^ sw) << 4));
+          acc[n] = Mma<bf16_t>::run(mi == 0 ? wa[kg] : wn[kg], xv, acc[n]);
+        }
+      // this m-tile's 16 fragments are dead from here: half of block 2's take their place while the stores / the next m-tile run
+      __builtin_amdgcn_sched_barrier(0);   // (not earlier: the fragment registers of three layers at once would spill)
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) w2[mi][kg] = a.wp2[(size_t)((2 * q2 + mi) * 8 + kg) * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < NP / 32; ++n) {
+        const int P1 = 4 * (32 * n + col) + (mt >> 2);
+        store_tile(acc[n], a.b1, 32 * (mt & 3), d1S, P1, 256, P1 & 15);
       }
-      const int P1 = 4 * col + (mt >> 2);
-      store_tile(acc, a.b1, 32 * (mt & 3), d1S, P1, 256, P1 & 15);
     }
   }
   __syncthreads();
   if (stamp) a.stamps[8 * sid + 2] = __builtin_amdgcn_s_memtime();
 
-  // ---- phase B: d2 = relu(W2 . d1): wave owns m-tile `wave` (n = q2 * 64 + co) for the four 32-pixel column tiles
-  {
-    uint4 wa[8];
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) wa[kg] = a.wp2[(size_t)(wave * 8 + kg) * 64 + lane];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int P1 = 32 * nt + col;
-      const char* xb = d1S + P1 * 256;
-      const int sw = P1 & 15;
-      f32x16_t acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int kg = 0; kg < 8; ++kg) {
-        const uint4 xv = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
-        acc = Mma<bf16_t>::run(wa[kg], xv, acc);
-      }
-      const int P2 = 4 * P1 + (wave >> 1);
-      store_tile(acc, a.b2, 32 * (wave & 1), d2S, P2, 128, (P2 >> 1) & 7);
-    }
-  }
-  __syncthreads();
-  if (stamp) a.stamps[8 * sid + 3] = __builtin_amdgcn_s_memtime();
-
-  // ---- phase C: d3 = relu(W3 . d2) in registers (m-tile = q3, all 32 channels of a pixel over the two lane halves), the
-  //      32 -> 1 transposed convolution, and the squared error against x
+  // ---- phases B + C, one register chain per wave, no LDS and no barrier between them.  A unit = (32 d1 pixels, q2): the wave
+  //      computes BOTH 32-channel halves of d2 for those pixels' q2 children (m-tiles 2 q2, 2 q2 + 1), so their 64 channels sit in
+  //      its own two accumulators; converted pairwise to bf16 they are the four k-steps of block 3's B operand ("accumulator as
+  //      the next operand": registers 8 s .. 8 s + 7 of half hf -> k-step 2 hf + s, channel order 8 (j >> 2) + 4 h + (j & 3)
+  //      inside a step -- W3's fragments are loaded in that same permuted order), d3 likewise feeds the 32 -> 1 layer.
   float err = 0.f;
   {
-    uint4 wa[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) wa[mt][kg] = a.wp3[(size_t)(mt * 4 + kg) * 64 + lane];
-    float b3v[16];
+    f32x16_t b3v;                                   // block 3's bias in accumulator layout: the C operand of a chain's first MFMA
 #pragma unroll
     for (int r = 0; r < 16; ++r) b3v[r] = a.b3[(r & 3) + 8 * (r >> 2) + 4 * h];
     uint4 w4f[4];                                   // [k-step 0: hi, lo][k-step 1: hi, lo]
 #pragma unroll
     for (int i = 0; i < 4; ++i) w4f[i] = a.w4pack[i * 64 + lane];
     const float b4 = a.b4[0];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int P2 = 32 * (2 * wave + ni) + col;
-      const char* xb = d2S + P2 * 128;
-      const int sw = (P2 >> 1) & 7;
-      uint4 xv[4];
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) xv[kg] = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
-      const int p = P2 >> 4, q1 = (P2 >> 2) & 3, q2 = P2 & 3;
-      const int g = g0 + p;
-      const bool valid = g < npx;
+    const void* const xu = (const char*)a.x + (int64_t)b * a.sb * (XBF ? 2 : 4);
+    const unsigned ust = (unsigned)a.st, usf = (unsigned)a.sf;
+#pragma unroll 1
+    for (int u = 0; u < NP / 16; ++u) {
+      const int nt = (wave >> 2) + 2 * u;
+      const int P1 = 32 * nt + col;
+      const int p = P1 >> 2, q1 = P1 & 3;
+      const bool valid = g0 + p < npx;
+      const int g = valid ? g0 + p : npx - 1;        // clamped: the loads below are unconditional, the error is masked
       const int i4 = g / a.W4, j4 = g - i4 * a.W4;
-      const int tq = 16 * i4 + 8 * (q1 >> 1) + 4 * (q2 >> 1), fq = 16 * j4 + 8 * (q1 & 1) + 4 * (q2 & 1);
+      const int tq = 16 * i4 + 8 * (q1 >> 1) + 4 * (q2 >> 1) + h, fq = 16 * j4 + 8 * (q1 & 1) + 4 * (q2 & 1);
+      // this lane's eight x values of the unit (rows tq, tq + 2; columns fq .. fq + 3), requested before the MFMA chain starts
+      float xr[4][2], mu4[4], sg4[4];
+      {
+        const unsigned o0 = (unsigned)tq * ust + (unsigned)fq * usf;   // 32-bit inside an utterance (cae_dec_fused_supports)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) xr[mt][c] = cdf_ldraw<XBF>(xu, o0 + 2u * (mt >> 1) * ust + (2u * (mt & 1) + c) * usf);
+        if constexpr (NORM) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { mu4[c] = a.mu[fq + c]; sg4[c] = a.sigma[fq + c]; }
+        }
+      }
+      uint4 dk[4];
+      {
+        const char* xb = d1S + P1 * 256;
+        const int sw = P1 & 15;
+        f32x16_t acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+          const uint4 xv = *(const uint4*)(xb + (((2 * kg + h) ^ sw) << 4));
+          acc0 = Mma<bf16_t>::run(w2[0][kg], xv, acc0);
+          acc1 = Mma<bf16_t>::run(w2[1][kg], xv, acc1);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int sI = 0; sI < 2; ++sI) {
+            unsigned pk[4];
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+              const float4 bv = *(const float4*)(b2S + 32 * hf + 16 * sI + 8 * gq + 4 * h);
+              const int r0 = 8 * sI + 4 * gq;
+              const f32x16_t& ac = hf ? acc1 : acc0;
+              pk[2 * gq] = pack_bf16x2(relu1(ac[r0] + bv.x, rlim), relu1(ac[r0 + 1] + bv.y, rlim));
+              pk[2 * gq + 1] = pack_bf16x2(relu1(ac[r0 + 2] + bv.z, rlim), relu1(ac[r0 + 3] + bv.w, rlim));
+            }
+            dk[2 * hf + sI] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          }
+      }
+      // W3 fragments come from LDS one m-tile ahead (all sixteen hoisted to the top of the unit would cost 64 registers and spill)
+      uint4 w3f[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w3f[kk] = w3S[kk * 64 + lane];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        f32x16_t acc;
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16_t acc = Mma<bf16_t>::run(w3f[0], dk[0], b3v);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int kk = 1; kk < 4; ++kk) acc = Mma<bf16_t>::run(w3f[kk], dk[kk], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt < 3) {
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) acc = Mma<bf16_t>::run(wa[mt][kg], xv[kg], acc);
-        // d3 = bf16(relu(acc + bias)) never leaves the registers: converted pairwise it IS the B operand of the 32 -> 1 layer
-        // (k-step s = registers 8 s .. 8 s + 7; the packed W4 image follows the same permuted channel order), W4 = hi + lo bf16:
-        // four MFMAs instead of 64 FMAs + 16 LDS reads + 4 cross-half exchanges per lane
+          for (int kk = 0; kk < 4; ++kk) w3f[kk] = w3S[((mt + 1) * 4 + kk) * 64 + lane];
+        }
         uint4 dfr[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int sI = 0; sI < 2; ++sI) {
           unsigned pk[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            pk[p] = pack_bf16x2(relu1(acc[8 * s + 2 * p] + b3v[8 * s + 2 * p], rlim), relu1(acc[8 * s + 2 * p + 1] + b3v[8 * s + 2 * p + 1], rlim));
-          dfr[s] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          for (int pp = 0; pp < 4; ++pp)
+            pk[pp] = pack_bf16x2(relu1(acc[8 * sI + 2 * pp], rlim), relu1(acc[8 * sI + 2 * pp + 1], rlim));
+          dfr[sI] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
         f32x16_t y;
 #pragma unroll
@@ -211,16 +280,18 @@ __global__ __launch_bounds__(512, 2) void cae_dec_fused_kernel(CaeDecFusedArgs a
         y = Mma<bf16_t>::run(w4f[2], dfr[1], y);
         // rows 4 h, 4 h + 1 of y = outputs (a4 = h, c4 = 0, 1) of this lane's pixel: registers 0, 1
         const float r0 = y[0] + b4, r1 = y[1] + b4;
-        const int t = tq + 2 * (mt >> 1) + h, f = fq + 2 * (mt & 1);
         if (valid) {
-          const float d0 = r0 - cdf_ldx(a, b, t, f), d1 = r1 - cdf_ldx(a, b, t, f + 1);
+          float x0 = xr[mt][0], x1 = xr[mt][1];
+          if constexpr (NORM) { x0 = (x0 - mu4[2 * (mt & 1)]) / sg4[2 * (mt & 1)]; x1 = (x1 - mu4[2 * (mt & 1) + 1]) / sg4[2 * (mt & 1) + 1]; }
+          const float d0 = r0 - x0, d1 = r1 - x1;
           err = fmaf(d0, d0, err);
           err = fmaf(d1, d1, err);
-          if (a.recon) *reinterpret_cast<float2*>(a.recon + ((size_t)b * a.T + t) * a.F + f) = make_float2(r0, r1);
+          if (a.recon) *reinterpret_cast<float2*>(a.recon + ((size_t)b * a.T + tq + 2 * (mt >> 1)) * a.F + fq + 2 * (mt & 1)) = make_float2(r0, r1);
         }
       }
     }
   }
+  if (stamp) a.stamps[8 * sid + 3] = __builtin_amdgcn_s_memtime();
   // ---- the output_padding columns (constants) and the zero rows t >= 16 H4: the utterance's last workgroup
   if (tile == a.ntile - 1) {
     const int HR = 16 * a.H4, f0 = 16 * a.W4, nstrip = HR * 4, ntail = (a.T - HR) * a.F;
@@ -305,6 +376,11 @@ hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float
   return hipGetLastError();
 }
 
+// the kernel addresses x inside one utterance with unsigned 32-bit element offsets
+bool cae_dec_fused_supports(int T, int F, int64_t st, int64_t sf) {
+  return st >= 0 && sf >= 0 && (int64_t)(T - 1) * st + (int64_t)(F - 1) * sf < ((int64_t)1 << 31);
+}
+
 int cae_dec_fused_tiles(int H4, int W4) { return (H4 * W4 + cdf::NP - 1) / cdf::NP; }
 
 hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* b1, const uint4* wp2, const float* b2, const uint4* wp3,
@@ -317,10 +393,14 @@ hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* 
   a.lat = (const bf16_t*)lat; a.wp1 = wp1; a.wp2 = wp2; a.wp3 = wp3; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.w4 = w4; a.b4 = b4; a.cst = cst;
   a.x = x; a.x_bf16 = x_dtype == DFA_DTYPE_BF16 ? 1 : 0; a.sb = sb; a.st = st; a.sf = sf; a.mu = mu; a.sigma = sigma;
   a.recon = recon; a.partial = partial; a.H4 = H4; a.W4 = W4; a.T = T; a.F = F; a.ntile = cae_dec_fused_tiles(H4, W4);
-  hipError_t e = hipFuncSetAttribute((const void*)cae_dec_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cdf::LDS_BYTES);
-  if (e != hipSuccess) return e;     // (per device: set on every launch, it is cheap)
-  hipLaunchKernelGGL(cae_dec_fused_kernel, dim3(a.ntile, B), dim3(512), cdf::LDS_BYTES, s, a);
-  return hipGetLastError();
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, cdf::LDS_BYTES);
+    if (e != hipSuccess) return e;     // (per device: set on every launch, it is cheap)
+    hipLaunchKernelGGL(kern, dim3(a.ntile, B), dim3(512), cdf::LDS_BYTES, s, a);
+    return hipGetLastError();
+  };
+  if (a.x_bf16) return mu ? go(cae_dec_fused_kernel<true, true>) : go(cae_dec_fused_kernel<true, false>);
+  return mu ? go(cae_dec_fused_kernel<false, true>) : go(cae_dec_fused_kernel<false, false>);
 }
 
 }  // namespace dfa

@@ -208,6 +208,7 @@ hipError_t launch_cae_dec_fused(const void* lat, const uint4* wp1, const float* 
                                 const float* b3, const float* w4, const float* b4, const uint4* w4pack, const float* cst, const void* x,
                                 int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma, float* recon,
                                 float* partial, int B, int H4, int W4, int T, int F, hipStream_t s, long long* stamps = nullptr);
+bool cae_dec_fused_supports(int T, int F, int64_t st, int64_t sf);
 hipError_t launch_pack_cae_dec4(const float* w4, uint4* pack, hipStream_t s);
 hipError_t launch_cae_mse_finalize(const float* partial, int nblk, float inv_n, float* mse, int B, hipStream_t s);
 // cnn1d_fused.hip: the whole CNN1D eval forward as one kernel (fp32 matrix cores, activations in LDS)

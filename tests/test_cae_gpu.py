@@ -166,7 +166,13 @@ def test_cae_fused_decoder_matches_four_launch_path(golden, B, T, F, xdt, view):
         ctx.set_option("cae_dec_fused", 1)
     assert torch.equal(got_l, ref_l)
     scale = max(1.0, float(ref_r.abs().max()))
-    assert float((got_r - ref_r).abs().max()) <= 2e-5 * scale, float((got_r - ref_r).abs().max())
+    # the fused kernel feeds d2 / d3 to the next layer straight from the accumulators, which permutes the channel order inside
+    # an MFMA k-step: same products, another fp32 summation order, so a d2 / d3 element sitting on a bf16 rounding boundary may
+    # land one bf16 ulp away (2^-8 relative, times |W|): isolated elements at ~1e-3, nothing systematic
+    diff = (got_r - ref_r).abs()
+    assert float(diff.max()) <= 3e-3 * scale, float(diff.max())
+    assert float(diff.mean()) <= 2e-6 * scale, float(diff.mean())
+    assert float((diff > 2e-5 * scale).float().mean()) <= 2e-3
     if T % 16:
         assert torch.all(got_r[:, 16 * (T // 16):, :] == 0)
     np.testing.assert_allclose(got_s.cpu().numpy(), ref_s.cpu().numpy(), rtol=2e-5)
