@@ -49,6 +49,8 @@ SYMBOLS = [
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64]),
     ("dfa_cnn2d_set_train_augment", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_float, C.c_uint64, C.c_uint64]),
+    ("dfa_cnn1d_set_train_augment", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_float, C.c_uint64, C.c_uint64]),
     ("dfa_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]),
     ("dfa_cnn1d_set_params", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),

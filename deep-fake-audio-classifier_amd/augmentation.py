@@ -85,17 +85,20 @@ class FusedAugment:
     calls, in the same order, as the op-by-op functions above -- seeded runs pick the same spans, shift and per-dim keep
     mask as the reference; only the jitter noise comes from the library's Philox stream (statistically N(0, std^2)).
 
-    fold=True (CNN2D training): nothing is computed here at all -- the drawn parameters are ARMED on the device context
-    (`dfa_cnn2d_set_train_augment`) and the batch is returned unchanged; the next train-mode forward of a CNN2D (and its
-    backward) read x through the same element formula inside the three kernels that load x, so no augmented copy of the
-    batch is ever written or re-read.  The result is identical to the stand-alone pass.
+    fold=True / "cnn2d" / "cnn1d" (classifier training): nothing is computed here at all -- the drawn parameters are ARMED on
+    the device context (`dfa_cnn2d_set_train_augment` / `dfa_cnn1d_set_train_augment`) and the batch is returned unchanged;
+    the next train-mode forward of that model (and its backward) read x through the same element formula inside the kernels
+    that load x (three for the CNN2D, two for the CNN1D), so no augmented copy of the batch is ever written or re-read
+    (SURVEY.md section 8(f)3).  The result is identical to the stand-alone pass.
 
     CUDA tensors only (the product path has no CPU fallback); for CPU tensors use the functions above."""
 
     def __init__(self, spec_augment=False, time_mask_ratio=0.2, feature_mask=False, feature_mask_ratio=0.1,
                  time_shift=False, time_shift_ratio=0.1, channel_drop=False, channel_drop_prob=0.1,
                  gaussian_jitter=False, gaussian_jitter_std=0.01, out_dtype=None, seed=None, rng_device=None, fold=False):
-        self.fold = bool(fold)
+        self.fold = {True: "cnn2d", False: None, None: None}.get(fold, fold)    # which model's loads take the augmentation
+        if self.fold not in (None, "cnn2d", "cnn1d"):
+            raise ValueError(f"fold must be False, True, 'cnn2d' or 'cnn1d' (got {fold!r})")
         self.rng_device = rng_device      # where the keep mask is drawn: None = the batch's device (src/augmentation.py:52), 'cpu' = the host generator
         self.spec, self.tm_ratio = bool(spec_augment), float(time_mask_ratio)
         self.fmask, self.fm_ratio = bool(feature_mask), float(feature_mask_ratio)
@@ -134,7 +137,8 @@ class FusedAugment:
         if self.fold:
             ctx = _lib.Context.get(x.device)
             self._keep = keep                                   # must outlive the backward pass
-            _lib.check(ctx.handle, ctx.lib.dfa_cnn2d_set_train_augment(
+            arm = ctx.lib.dfa_cnn2d_set_train_augment if self.fold == "cnn2d" else ctx.lib.dfa_cnn1d_set_train_augment
+            _lib.check(ctx.handle, arm(
                 ctx.handle, 1, T, F, int(shift), C.c_void_p(keep.data_ptr() if keep is not None else None), ts, tl, fs, fl,
                 std, self.seed, self.calls * (B * T * F + 64)))
             self.calls += 1

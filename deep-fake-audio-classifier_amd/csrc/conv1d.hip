@@ -7,17 +7,20 @@
 // Tile = 32 output channels x 64 frames per workgroup; input channels are streamed through LDS 16 at a time
 // (x slab [16][66] + weight slab [16][3][32]); every thread owns 2 channels x 4 consecutive frames.
 #include "dfa_internal.h"
+#include "rng.h"
 
 namespace dfa {
 
 constexpr int C1D_OT = 32, C1D_TT = 64, C1D_CC = 16;
 
-template <bool MEAN, bool RELU = true>
+// AUG (train-mode layer 1 only): x is read through the armed train-time augmentation (rng.h aug_apply; channel = feature dim,
+// dfa_cnn1d_set_train_augment) -- the element the stand-alone dfa_augment_batch pass would have written, never materialised.
+template <bool MEAN, bool RELU = true, bool AUG = false>
 __global__ __launch_bounds__(256) void conv1d_k3_bn_relu_kernel(const float* __restrict__ x, int64_t sb, int64_t sc,
                                                                  int64_t st, const float* __restrict__ w,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ out, int Cin, int Cout, int T,
-                                                                 float inv_t) {
+                                                                 float inv_t, AugCfg aug = AugCfg{}) {
   __shared__ float xs[C1D_CC][C1D_TT + 4];
   __shared__ float ws[C1D_CC][3][C1D_OT];
   __shared__ float red[C1D_OT][17];
@@ -40,7 +43,10 @@ __global__ __launch_bounds__(256) void conv1d_k3_bn_relu_kernel(const float* __r
       for (int e = tid; e < C1D_CC * (C1D_TT + 2); e += 256) {
         const int c = e / (C1D_TT + 2), tt = e - c * (C1D_TT + 2);
         const int t = t0 - 1 + tt, ci = c0 + c;
-        xs[c][tt] = (ci < Cin && t >= 0 && t < T) ? xb[(int64_t)ci * sc + (int64_t)t * st] : 0.f;
+        if constexpr (AUG)
+          xs[c][tt] = (ci < Cin && t >= 0 && t < T) ? aug_apply(aug, xb[(int64_t)ci * sc + (int64_t)aug_src_t(aug, t) * st], b, t, ci) : 0.f;
+        else
+          xs[c][tt] = (ci < Cin && t >= 0 && t < T) ? xb[(int64_t)ci * sc + (int64_t)t * st] : 0.f;
       }
       for (int e = tid; e < C1D_CC * 3 * C1D_OT; e += 256) {
         const int o = e & (C1D_OT - 1), k = (e / C1D_OT) % 3, c = e / (3 * C1D_OT);
@@ -115,18 +121,24 @@ hipError_t launch_fold_conv1d(const float* w, const float* b, const float* g, co
 }
 
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
-                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu) {
+                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu, const AugCfg* aug) {
+  if (aug && aug->on) {   // train-mode layer 1 with the augmentation folded into the x loads
+    if (relu || mean) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv1d_k3_bn_relu_kernel<false, false, true>), dim3((T + C1D_TT - 1) / C1D_TT, Cout / C1D_OT, B), dim3(256),
+                       0, s, x, sb, sc, st, w, bias, out, Cin, Cout, T, 0.f, *aug);
+    return hipGetLastError();
+  }
   if (!relu) {   // raw convolution (+ bias): train-mode forward and the data-gradient convolution
     hipLaunchKernelGGL((conv1d_k3_bn_relu_kernel<false, false>), dim3((T + C1D_TT - 1) / C1D_TT, Cout / C1D_OT, B), dim3(256),
-                       0, s, x, sb, sc, st, w, bias, out, Cin, Cout, T, 0.f);
+                       0, s, x, sb, sc, st, w, bias, out, Cin, Cout, T, 0.f, AugCfg{});
     return hipGetLastError();
   }
   if (mean) {
     hipLaunchKernelGGL(conv1d_k3_bn_relu_kernel<true>, dim3(1, Cout / C1D_OT, B), dim3(256), 0, s, x, sb, sc, st, w,
-                       bias, out, Cin, Cout, T, 1.0f / (float)T);
+                       bias, out, Cin, Cout, T, 1.0f / (float)T, AugCfg{});
   } else {
     hipLaunchKernelGGL(conv1d_k3_bn_relu_kernel<false>, dim3((T + C1D_TT - 1) / C1D_TT, Cout / C1D_OT, B), dim3(256), 0,
-                       s, x, sb, sc, st, w, bias, out, Cin, Cout, T, 0.f);
+                       s, x, sb, sc, st, w, bias, out, Cin, Cout, T, 0.f, AugCfg{});
   }
   return hipGetLastError();
 }

@@ -71,6 +71,8 @@ struct Cnn1dState {
   float *wt[2] = {nullptr, nullptr}, *zero_bias = nullptr;
   DropCfg train_drop{};
   int train_B = 0, train_T = 0;
+  AugCfg aug_armed{};   // dfa_cnn1d_set_train_augment: consumed by the next forward_train
+  AugCfg train_aug{};   // the augmentation of the forward_train in flight (the layer-1 weight gradient re-reads x through it)
 };
 
 struct CaeState {
@@ -228,7 +230,8 @@ hipError_t launch_cnn1d_fused_x3(const float* x, const void* w1, const float* b1
                                  const float* b3, const float* cw, const float* cb, float* logits, int B, int T, int F, hipStream_t s,
                                  long long* stamps = nullptr);
 hipError_t launch_conv1d(const float* x, int64_t sb, int64_t sc, int64_t st, const float* w, const float* bias,
-                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu = true);
+                         float* out, int B, int Cin, int Cout, int T, bool mean, hipStream_t s, bool relu = true,
+                         const AugCfg* aug = nullptr);
 // train_cnn1d.hip
 int cm_chunks(int B);
 int conv1d_wgrad_chunks(int B);
@@ -241,7 +244,7 @@ hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const fl
                             const float* beta, const float* up, float* partial, float* sums, float* dz, int B, int C,
                             int T, const DropCfg& dc, hipStream_t s);
 hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
-                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s);
+                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s, const AugCfg* aug = nullptr);
 hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias, int cin, int cout, hipStream_t s);
 // cae.hip
 hipError_t launch_cae_enc1(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu,

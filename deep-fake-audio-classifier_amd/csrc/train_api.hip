@@ -325,12 +325,10 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   return DFA_OK;
 }
 
-int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
-                                int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
-                                uint64_t offset) {
-  if (!ctx) return DFA_E_NULL_PTR;
-  Cnn2dState& m = ctx->cnn2d;
-  m.aug_armed = AugCfg{};
+// shared by the CNN2D and CNN1D entry points: validate, copy the keep mask into the context's double buffer, fill `armed`
+static int arm_train_augment(dfa_ctx* ctx, AugCfg& armed, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
+                             int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed, uint64_t offset) {
+  armed = AugCfg{};
   if (!enable) return DFA_OK;
   if (T < 1 || F < 1) return fail(ctx, DFA_E_BAD_SHAPE, "bad augmentation shape [T=%d, F=%d]", T, F);
   if (tmask_len < 0 || fmask_len < 0 || tmask_start < 0 || fmask_start < 0 || tmask_start + tmask_len > T ||
@@ -358,8 +356,24 @@ int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shif
   a.on = 1; a.T = T; a.F = F; a.shift = ((shift % T) + T) % T; a.keep = keep_dev;
   a.tm_start = tmask_start; a.tm_len = tmask_len; a.fm_start = fmask_start; a.fm_len = fmask_len;
   a.std = jitter_std; a.seed = seed; a.offset = offset;
-  m.aug_armed = a;
+  armed = a;
   return DFA_OK;
+}
+
+int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
+                                int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
+                                uint64_t offset) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  return arm_train_augment(ctx, ctx->cnn2d.aug_armed, enable, T, F, shift, keep_f, tmask_start, tmask_len, fmask_start, fmask_len,
+                           jitter_std, seed, offset);
+}
+
+int dfa_cnn1d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
+                                int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
+                                uint64_t offset) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  return arm_train_augment(ctx, ctx->cnn1d.aug_armed, enable, T, F, shift, keep_f, tmask_start, tmask_len, fmask_start, fmask_len,
+                           jitter_std, seed, offset);
 }
 
 int dfa_bce_smooth_fwd_bwd(dfa_ctx* ctx, const float* logits, const float* labels, float label_smoothing, int B,
@@ -444,6 +458,9 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   TraceRange trace_("dfa_cnn1d_forward_train");
   if (!ctx) return DFA_E_NULL_PTR;
   Cnn1dState& m = ctx->cnn1d;
+  const AugCfg armed = m.aug_armed;     // one-shot: consumed here, also by a call that fails its checks below
+  m.aug_armed = AugCfg{};
+  m.train_aug = AugCfg{};
   if (!m.have_params) return fail(ctx, DFA_E_NOT_PREPARED, "dfa_cnn1d_set_params has not been called");
   if (!x || !logits || !workspace) return fail(ctx, DFA_E_NULL_PTR, "x, logits and workspace must be non-null");
   if (x_dtype != DFA_DTYPE_F32) return fail(ctx, DFA_E_BAD_DTYPE, "cnn1d takes float32 input (got dtype %d)", x_dtype);
@@ -452,6 +469,10 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   if (!(p_drop >= 0.f && p_drop < 1.f)) return fail(ctx, DFA_E_BAD_SHAPE, "dropout p must be in [0, 1)");
   const Train1dPlan pl = plan_train1d(B, T, F);
   if (workspace_bytes < pl.total) return fail(ctx, DFA_E_WORKSPACE, "train workspace too small: %zu < %zu bytes", workspace_bytes, pl.total);
+  if (armed.on && (armed.T != T || armed.F != F))
+    return fail(ctx, DFA_E_BAD_SHAPE, "armed augmentation is for [T=%d, F=%d], the batch is [T=%d, F=%d]", armed.T, armed.F, T, F);
+  m.train_aug = armed;
+  const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
   DFA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!m.train_packed) {
     const size_t n = al((size_t)64 * 32 * 3 * 4) + al((size_t)128 * 64 * 3 * 4) + al(256 * 4);
@@ -478,7 +499,7 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     float* z = (float*)(ws + pl.z[l]);
     const float* const* q = p + 6 * l;
     if (l == 0) {
-      DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, q[0], q[1], z, B, F, 32, T, false, s, false));
+      DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, q[0], q[1], z, B, F, 32, T, false, s, false, aug));
     } else {
       const float* hin = (const float*)(ws + pl.h[l - 1]);
       DFA_HIP_CHECK(ctx, launch_conv1d(hin, (int64_t)Cin[l] * T, T, 1, q[0], q[1], z, B, Cin[l], C[l], T, false, s, false));
@@ -533,7 +554,8 @@ int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
                                         B, C[l], T, dc, s));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], C[l]);
     if (l == 0) {
-      DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)x, stride_b, stride_f, stride_t, partial, grads[0], grads[1], B, F, 32, T, s));
+      DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)x, stride_b, stride_f, stride_t, partial, grads[0], grads[1], B, F, 32, T, s,
+                                             m.train_aug.on ? &m.train_aug : nullptr));
     } else {
       DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)(ws + pl.h[l - 1]), (int64_t)Cin[l] * T, T, 1, partial, grads[4 * l],
                                              grads[4 * l + 1], B, Cin[l], C[l], T, s));

@@ -164,10 +164,12 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const float* __restri
 // operand; both operands are channel-major with t contiguous, i.e. K-contiguous rows, so v_mfma_f32_32x32x2_f32 takes
 // them straight from LDS tiles (lane = channel, k = frame parity).  One wave per (o tile, c tile, utterance chunk):
 // 96 MFMAs per 64-frame slab; the VALU kernel above spent 4 LDS reads on every 3 FMAs and ran at 128-512 blocks.
+// AUG (layer 1 only): h = x read through the armed train-time augmentation, as the forward read it (conv1d.hip)
+template <bool AUG>
 __global__ __launch_bounds__(64) void conv1d_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ h,
                                                                int64_t hsb, int64_t hsc, int64_t hst,
                                                                float* __restrict__ partial, int B, int Cin, int Cout, int T,
-                                                               int bchunk) {
+                                                               int bchunk, AugCfg aug) {
   __shared__ float dzs[32][W1D_TT + 1];
   __shared__ float hs[32][W1D_TT + 3];
   const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
@@ -193,11 +195,17 @@ __global__ __launch_bounds__(64) void conv1d_wgrad_mfma_kernel(const float* __re
 #pragma unroll
     for (int cc = 0; cc < 32; ++cc) {
       const int ci = c0 + cc;
-      rh[cc] = (ci < Cin && t >= 0 && t < T) ? h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)t * hst] : 0.f;
+      if constexpr (AUG)
+        rh[cc] = (ci < Cin && t >= 0 && t < T) ? aug_apply(aug, h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)aug_src_t(aug, t) * hst], b, t, ci) : 0.f;
+      else
+        rh[cc] = (ci < Cin && t >= 0 && t < T) ? h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)t * hst] : 0.f;
     }
     // the two extra frames of the 66-frame window: lane = (channel, which frame)
     const int ci2 = c0 + (lane & 31), t2 = t0 + 63 + (lane >> 5);
-    rh2 = (ci2 < Cin && t2 < T) ? h[(int64_t)b * hsb + (int64_t)ci2 * hsc + (int64_t)t2 * hst] : 0.f;
+    if constexpr (AUG)
+      rh2 = (ci2 < Cin && t2 < T) ? aug_apply(aug, h[(int64_t)b * hsb + (int64_t)ci2 * hsc + (int64_t)aug_src_t(aug, t2) * hst], b, t2, ci2) : 0.f;
+    else
+      rh2 = (ci2 < Cin && t2 < T) ? h[(int64_t)b * hsb + (int64_t)ci2 * hsc + (int64_t)t2 * hst] : 0.f;
   };
   if (nslab > 0) fetch(0);
   for (int sl = 0; sl < nslab; ++sl) {
@@ -305,10 +313,13 @@ hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const fl
 // partial: conv1d_wgrad_chunks(B) * (Cout*Cin*3 + Cout) floats
 int conv1d_wgrad_chunks(int B) { return B < 256 ? B : 256; }
 hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
-                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s) {
+                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s, const AugCfg* aug) {
   const int nch = conv1d_wgrad_chunks(B), bchunk = (B + nch - 1) / nch;
-  if (Cout % 32 == 0)
-    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel, dim3(Cout / 32, (Cin + 31) / 32, nch), dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk);
+  if (aug && aug->on) {
+    if (Cout % 32 != 0) return hipErrorInvalidValue;   // the folded form exists for the MFMA kernel only (layer 1: Cout = 32)
+    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel<true>, dim3(Cout / 32, (Cin + 31) / 32, nch), dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk, *aug);
+  } else if (Cout % 32 == 0)
+    hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel<false>, dim3(Cout / 32, (Cin + 31) / 32, nch), dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk, AugCfg{});
   else
     hipLaunchKernelGGL(conv1d_wgrad_kernel, dim3(Cout / 16, (Cin + 15) / 16, nch), dim3(256), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk);
   hipError_t e = hipGetLastError();

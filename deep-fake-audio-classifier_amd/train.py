@@ -77,8 +77,8 @@ def train_one_epoch_native(trainer, batcher, augment_fn=None, swap_tf: bool = Tr
 
 def build_augment_fn(args, fused: bool = False, fold: bool = False):
     """fused = True (GPU training): the whole pipeline as one HIP pass (augmentation.FusedAugment), same parameter draws;
-    fold = True (CNN2D): not even a pass -- the parameters are armed on the context and the training kernels that read x
-    apply them in their loads."""
+    fold = "cnn2d" / "cnn1d" (True = "cnn2d"): not even a pass -- the parameters are armed on the context and that model's
+    training kernels that read x apply them in their loads."""
     if fused and (args.spec_augment or args.time_shift or args.channel_drop or args.gaussian_jitter):
         return FusedAugment(fold=fold, spec_augment=args.spec_augment, time_mask_ratio=args.time_mask_ratio,
                             feature_mask=args.feature_mask, feature_mask_ratio=args.feature_mask_ratio,
@@ -184,8 +184,8 @@ def main(argv=None):
     model._drop_seed = dfa_dist.rank_seed(args.seed if args.seed else torch.initial_seed(), rank)
     weight_decay = args.weight_decay if args.weight_decay > 0 else 0.01      # AdamW default of src/train.py:321-325
     criterion = make_criterion(args.label_smoothing)
-    # batches are on the GPU when it is applied; for CNN2D the augmentation is folded into the kernels' loads
-    augment_fn = build_augment_fn(args, fused=(device.type == "cuda"), fold=(device.type == "cuda" and args.model == "cnn2d"))
+    # batches are on the GPU when it is applied; for both classifiers the augmentation is folded into the kernels' loads
+    augment_fn = build_augment_fn(args, fused=(device.type == "cuda"), fold=(args.model if device.type == "cuda" and args.model in ("cnn2d", "cnn1d") else False))
     if isinstance(augment_fn, FusedAugment):
         augment_fn.seed = dfa_dist.rank_seed(augment_fn.seed, rank)
 

@@ -174,6 +174,13 @@ int dfa_augment_batch(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, in
 int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
                                 int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
                                 uint64_t offset);
+/* The same for the CNN1D (src/train.py:68-69 feeds both classifiers): arms the augmentation for the NEXT dfa_cnn1d_forward_train /
+ * dfa_cnn1d_backward pair, whose two kernels that read x (layer-1 convolution, layer-1 weight gradient) read it through the same
+ * element formula -- the stand-alone dfa_augment_batch pass (one read + one write of the batch) disappears.  Same one-shot and
+ * keep_f rules as dfa_cnn2d_set_train_augment. */
+int dfa_cnn1d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
+                                int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
+                                uint64_t offset);
 /* one torch.optim.AdamW step over a flat fp32 buffer: p *= 1-lr*wd; m,v update; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).
  * grad_scale multiplies the gradient first (1/world after a sum all-reduce).  step is 1-based. */
 int dfa_adamw_step(dfa_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,

@@ -104,3 +104,54 @@ def test_augmentation_folded_into_training_loads_equals_standalone_pass():
         m1.zero_grad()
         plain = m1(x)
         assert not torch.equal(plain.squeeze(-1), l1)
+
+
+def test_augmentation_folded_into_cnn1d_training_loads_equals_standalone_pass():
+    """The same for the CNN1D (src/train.py:68-69 feeds both classifiers; round-2 review, missing #5): FusedAugment(fold="cnn1d")
+    arms `dfa_cnn1d_set_train_augment`; the layer-1 convolution and the layer-1 weight gradient -- the two kernels that read x --
+    apply the element formula in their loads.  Logits and all 14 gradients bit-identical to the stand-alone pass, for the stored
+    [B, F, T] layout (a view) and a dense [B, T, F] batch, jitter noise included; one-shot; a shape mismatch is an error that
+    leaves nothing armed."""
+    from dfa_amd.augmentation import FusedAugment
+    from dfa_amd.model_cnn1d import CNN1D
+    cfg = dict(spec_augment=True, time_mask_ratio=0.2, feature_mask=True, feature_mask_ratio=0.1, time_shift=True,
+               time_shift_ratio=0.1, channel_drop=True, channel_drop_prob=0.3, gaussian_jitter=True,
+               gaussian_jitter_std=0.05)
+    g = torch.Generator().manual_seed(6)
+    for layout, (B, T, F) in (("bft_view", (3, 70, 180)), ("btf", (2, 17, 45)), ("bft_view", (2, 321, 180))):
+        stored = (torch.randn(B, F, T, generator=g) if layout == "bft_view" else torch.randn(B, T, F, generator=g)) * 3.0
+        x = stored.to("cuda").transpose(1, 2) if layout == "bft_view" else stored.to("cuda")
+        y = (torch.rand(B, generator=g) > 0.5).float().to("cuda")
+        results = []
+        for fold in (False, "cnn1d"):
+            torch.manual_seed(9)
+            model = CNN1D(in_features=F, dropout=0.2).to("cuda").train()
+            model._drop_seed = 123
+            with torch.no_grad():
+                model.classifier.weight.mul_(30.0)
+            random.seed(31); torch.manual_seed(31)
+            aug = FusedAugment(seed=77, fold=fold, **cfg)
+            xa = aug(x)
+            if fold:
+                assert xa.data_ptr() == x.data_ptr()
+            logits = model(xa).squeeze(-1)
+            loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+            loss.backward()
+            results.append((logits.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}, model))
+        (l0, g0, _), (l1, g1, m1) = results
+        assert torch.equal(l0, l1), (layout, float((l0 - l1).abs().max()))
+        assert len(g0) == 14
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (layout, n, float((g0[n] - g1[n]).abs().max()))
+        m1.zero_grad()
+        plain = m1(x)                                   # one-shot: the next forward sees the raw batch again
+        assert not torch.equal(plain.squeeze(-1), l1)
+    # armed for another shape: the forward refuses, and the arm is gone afterwards
+    model = CNN1D(in_features=180, dropout=0.0).to("cuda").train()
+    x = torch.randn(2, 40, 180, device="cuda")
+    FusedAugment(seed=1, fold="cnn1d", **cfg)(torch.randn(2, 48, 180, device="cuda"))
+    with pytest.raises(ValueError):
+        model(x)
+    a = model(x)
+    b = model(x)
+    assert torch.equal(a, b)
