@@ -19,6 +19,7 @@
 // cnn1d_fused.hip / the three-launch path (api.hip).
 #include "dfa_internal.h"
 #include "conv3x3_mfma.h"
+#include "rng.h"
 
 namespace dfa {
 namespace c1x {
@@ -382,6 +383,275 @@ static void cnn1d_x3_layout(int T, int F, int* offB, int* total, int* slab_float
   *slab_floats = SL;
 }
 // x must be the contiguous [B][F][T] storage (element (b, t, f) at b F T + f T + t), 16-byte aligned
+// ---- one Conv1d(k = 3, pad 1) layer of the TRAINING step on the matrix cores (src/train.py:71-76 through
+// src/model_cnn1d.py:17-34): z[b][co][t] = bias[co] + sum_{ci, k} W[co][ci][k] in[b][ci][t + k - 1], channel-major fp32 in and
+// out, no BatchNorm / ReLU (train mode: batch statistics come first).  It serves the three forward convolutions and -- on the
+// flipped / transposed weight image of conv1d_dgrad_pack_kernel -- the two data gradients.  Layer 1 of the fused kernel above,
+// generalised: a workgroup = (utterance, MT tiles of 32 output channels); 16-channel slabs of the input go through LDS as they are
+// (contiguous 16 T floats, 16-byte loads, two slabs ahead), the lane that owns frame t splits x[c][t-1..t+1] of its 8 channels
+// into bf16 B fragments ONCE per slab and tap and feeds them to every channel tile; this layer's A fragments sit in LDS.
+// TERMS = 3 (default): every fp32 operand = hi + lo + lo2, three bf16 terms = its 24-bit mantissa exactly, six MFMAs per product
+// (all term pairs of order <= 2; the dropped ones are below 2^-24 of a product): fp32-grade sums.  TERMS = 2: the bf16x3
+// construction of the eval kernel (16-bit operands, three MFMAs, ~1e-5) -- fine for inference's 1e-4 bar, but in a training step
+// a 1e-5 perturbation of a pre-activation flips ~1e-5 of the ReLU masks and every flip moves a gradient by a whole element:
+// relative L2 error ~ sqrt(1e-5) = 3e-3 against 3e-4 for fp32 arithmetic (tools/gpu_cnn1d_x3_probe.py), so it is opt-in.
+// The fp32 VALU kernel this replaces (conv1d.hip) needs 97 us per call at [256, *, 321].
+struct Conv1dX3Args {
+  const float* x;              // [B] x [Cin][T] contiguous per utterance, utterance stride sb floats, 16-byte aligned
+  int64_t sb;
+  const uint4* w;              // pack_conv1d_terms_kernel image [Cout / 32][3][nks][TERMS][64]
+  const float* bias;           // [Cout]
+  float* z;                    // [B][Cout][T]
+  int T, Cin, Cout, NT, nks, slab_floats, offW;
+  AugCfg aug;                  // AUG instantiation (training layer 1): x is read through the armed train-time augmentation (rng.h)
+};
+
+// A-fragment images with TERMS bf16 terms per weight: wx[m][tap][ks][term][lane]
+__global__ void pack_conv1d_terms_kernel(const float* __restrict__ wf, uint4* __restrict__ wx, int cin, int cout, int nks, int terms) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int total = (cout / 32) * 3 * nks * 64;
+  if (i >= total) return;
+  const int lane = i & 63;
+  int rest = i >> 6;
+  const int ks = rest % nks; rest /= nks;
+  const int tap = rest % 3, m = rest / 3;
+  const int co = 32 * m + (lane & 31), hh = lane >> 5;
+  bf16_t t0[8], t1[8], t2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = 16 * ks + 8 * hh + j;
+    const float w = ci < cin ? wf[((size_t)co * cin + ci) * 3 + tap] : 0.f;
+    t0[j] = float_to_bf16(w);
+    const float r1 = w - bf16_to_float(t0[j]);
+    t1[j] = float_to_bf16(r1);
+    t2[j] = float_to_bf16(r1 - bf16_to_float(t1[j]));
+  }
+  uint4* dst = wx + ((size_t)((m * 3 + tap) * nks + ks) * terms) * 64 + lane;
+  dst[0] = *reinterpret_cast<const uint4*>(t0);
+  dst[64] = *reinterpret_cast<const uint4*>(t1);
+  if (terms == 3) dst[128] = *reinterpret_cast<const uint4*>(t2);
+}
+size_t conv1d_terms_pack_bytes(int cin, int cout, int terms) { return (size_t)(cout / 32) * 3 * cnn1d_x3_nks(cin) * terms * 64 * 16; }
+hipError_t launch_pack_conv1d_terms(const float* wf, void* wx, int cin, int cout, int terms, hipStream_t s) {
+  const int total = (cout / 32) * 3 * cnn1d_x3_nks(cin) * 64;
+  hipLaunchKernelGGL(pack_conv1d_terms_kernel, dim3((total + 255) / 256), dim3(256), 0, s, wf, (uint4*)wx, cin, cout, cnn1d_x3_nks(cin), terms);
+  return hipGetLastError();
+}
+
+// 8 floats -> TERMS bf16 fragments (element j in bf16 position j): v = f[0] + f[1] (+ f[2]), exactly for TERMS = 3
+template <int TERMS>
+__device__ __forceinline__ void split8n(const float (&v)[8], uint4 (&f)[TERMS]) {
+  unsigned q[TERMS][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float r0 = v[2 * p], r1 = v[2 * p + 1];
+#pragma unroll
+    for (int t = 0; t < TERMS; ++t) {
+      q[t][p] = pack_bf16x2(r0, r1);
+      if (t + 1 < TERMS) { r0 -= __uint_as_float(q[t][p] << 16); r1 -= __uint_as_float(q[t][p] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TERMS; ++t) f[t] = make_uint4(q[t][0], q[t][1], q[t][2], q[t][3]);
+}
+
+template <int MT, int TERMS, bool AUG = false>
+__global__ __launch_bounds__(512) void conv1d_x3_kernel(Conv1dX3Args a) {
+  using namespace c1x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x, m0 = blockIdx.y * MT;
+  const int T = a.T, NT = a.NT, nks = a.nks;
+  float* const slab0 = (float*)smem;                      // two slabs of slab_floats floats: [4 pad][16 x T][4 pad]
+  char* const wS = smem + a.offW;                         // this workgroup's A fragments [MT][3][nks][TERMS][64] x 16 B
+  f32x16_t acc[MT][MAXT1];
+  const float4* xg = (const float4*)(a.x + (size_t)b * a.sb);
+  const int SL = a.slab_floats;
+  constexpr int NLD = 3;                                   // 16 T / 4 float4 per slab <= 1536 = 3 x 512
+  float4 xrA[NLD], xrB[NLD];
+  const int nreal = (a.Cin + 15) / 16;                     // slabs that exist (nks may be one more: a zero slab)
+  auto slab_n4 = [&](int s) { return max(0, min(16, a.Cin - 16 * s)) * T / 4; };
+  auto slab_load = [&](int s, float4 (&xr)[NLD]) {         // unconditional, clamped (see the fused kernel)
+    const int sc = min(s, nreal - 1), n4 = slab_n4(sc);
+    if constexpr (AUG) {
+      // element (channel = feature dim f, frame t) of the augmented batch: the source frame is rolled, so the slab is gathered
+      // element by element (4 dword loads per float4 slot) and finished by aug_apply -- the value dfa_augment_batch would write
+      const float* xf = a.x + (size_t)b * a.sb;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = min(k * NTH + tid, n4 - 1);
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int flat = 4 * i + u, c = flat / T, t = flat - c * T, f = 16 * sc + c;
+          e[u] = aug_apply(a.aug, xf[(size_t)f * T + aug_src_t(a.aug, t)], b, t, f);
+        }
+        xr[k] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    } else {
+      const float4* src = xg + (size_t)4 * sc * T;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) xr[k] = src[min(k * NTH + tid, n4 - 1)];
+    }
+  };
+  auto slab_store = [&](int s, const float4 (&xr)[NLD]) {
+    float* dst = slab0 + (s & 1) * SL + 4;
+    const int n4 = slab_n4(s);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = k * NTH + tid;
+      const unsigned m = i < n4 ? 0xffffffffu : 0u;
+      const float4 v = xr[k];
+      if (i < 4 * T)
+        *(uint4*)(dst + 4 * i) = make_uint4(__float_as_uint(v.x) & m, __float_as_uint(v.y) & m, __float_as_uint(v.z) & m, __float_as_uint(v.w) & m);
+    }
+  };
+  slab_load(0, xrA);
+  slab_load(1, xrB);
+  {
+    const int n = MT * 3 * nks * TERMS * 64;
+    const uint4* wsrc = a.w + (size_t)m0 * 3 * nks * TERMS * 64;
+    for (int i = tid; i < n; i += NTH) *(uint4*)(wS + (size_t)i * 16) = wsrc[i];
+    if (tid < 16) {
+      const int sbuf = tid >> 3, e = tid & 7;
+      slab0[sbuf * SL + (e < 4 ? e : 16 * T + e)] = 0.f;
+    }
+  }
+  slab_store(0, xrA);
+  __syncthreads();
+
+  const int nmine = (NT - wave + NW - 1) / NW;
+  unsigned tin[MAXT1][3];                                  // all-ones where tap k of this lane's frame exists, else 0
+  int tl[MAXT1];
+#pragma unroll
+  for (int j = 0; j < MAXT1; ++j) {
+    const int t = TW * (wave + NW * j) + col;
+    tl[j] = t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tin[j][k] = ((j < nmine) && t < T && t - 1 + k >= 0 && t - 1 + k < T) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+  }
+  // one slab = one k-step of 16 channels: trip s computes slab s from buffer s & 1, requests slab s + 2 and parks slab s + 1
+  // (requested a trip ago) in the other buffer; one barrier per trip.  Inside a trip the TAP is the outer loop: its MT x TERMS
+  // weight fragments are read from LDS once and serve both of the wave's frame tiles.
+  auto trip = [&](int s, float4 (&xr_next)[NLD], float4 (&xr_far)[NLD], bool load) {
+    if (load) slab_load(s + 2, xr_far);
+    const float* sl = slab0 + (s & 1) * SL + 4 + 8 * h * T - 1;       // this lane half's 8 channels, frame index - 1
+    float v[MAXT1][3][8];
+#pragma unroll
+    for (int j = 0; j < MAXT1; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[j][k][c] = sl[c * T + tl[j] + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint4 w[MT][TERMS];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) w[m][p] = *(const uint4*)(wS + ((size_t)((((m * 3 + k) * nks + s) * TERMS + p) * 64 + lane)) * 16);
+#pragma unroll
+      for (int j = 0; j < MAXT1; ++j) {
+        uint4 xs[TERMS];
+        split8n<TERMS>(v[j][k], xs);
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p) xs[p] = and4(tin[j][k], xs[p]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if constexpr (TERMS == 3) {                      // smallest terms first
+            acc[m][j] = mma_bf16(w[m][2], xs[0], acc[m][j]);
+            acc[m][j] = mma_bf16(w[m][0], xs[2], acc[m][j]);
+            acc[m][j] = mma_bf16(w[m][1], xs[1], acc[m][j]);
+          }
+          acc[m][j] = mma_bf16(w[m][1], xs[0], acc[m][j]);
+          acc[m][j] = mma_bf16(w[m][0], xs[1], acc[m][j]);
+          acc[m][j] = mma_bf16(w[m][0], xs[0], acc[m][j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slab_store(s + 1, xr_next);
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 2 < nks; s += 2) {                              // nks is even
+    trip(s, xrB, xrA, true);
+    trip(s + 1, xrA, xrB, true);
+  }
+  trip(s, xrB, xrA, false);
+  trip(s + 1, xrA, xrB, false);
+
+  // ---- + bias, channel-major store: register r = channel (r&3) + 8 (r>>2) + 4 h of frame t = lane: 32 lanes write 128 contiguous bytes
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int cb = 32 * (m0 + m) + 4 * h;
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = a.bias[cb + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int j = 0; j < MAXT1; ++j) {
+      const int t = tl[j];
+      if (j < nmine && t < T) {
+        float* zr = a.z + ((size_t)b * a.Cout + cb) * T + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zr[(size_t)((r & 3) + 8 * (r >> 2)) * T] = acc[m][j][r] + bv[r];
+      }
+    }
+  }
+}
+
+static void conv1d_x3_layout(int T, int cin, int mt, int terms, int* offW, int* total, int* slab_floats) {
+  const int sl = 16 * T + 8;
+  *slab_floats = sl;
+  *offW = (2 * sl * 4 + 255) & ~255;
+  *total = *offW + mt * 3 * cnn1d_x3_nks(cin) * terms * 64 * 16;
+}
+// channel tiles per workgroup: two when the layer has them and their fragments fit beside the slabs; mode 2 (diagnostic) forces one
+static int conv1d_x3_mt(int T, int cin, int cout, int terms, int mode) {
+  if (mode == 2 || cout % 64 != 0) return 1;
+  int offW, total, sl;
+  conv1d_x3_layout(T, cin, 2, terms, &offW, &total, &sl);
+  return total <= 160 * 1024 ? 2 : 1;
+}
+
+bool conv1d_x3_supports(const float* x, int64_t sb, int64_t sc, int64_t st, const float* z, int T, int Cin, int Cout, int terms) {
+  if (T < 3 || T > 384 || (T + 31) / 32 > c1x::NW * c1x::MAXT1 || Cin < 1 || (Cin & 3) || Cout < 32 || (Cout & 31)) return false;
+  if (st != 1 || sc != T || (sb & 3) || ((uintptr_t)x & 15) || ((uintptr_t)z & 3)) return false;
+  if ((cnn1d_x3_nks(Cin) & 1) || (terms != 2 && terms != 3)) return false;
+  int offW, total, sl;
+  conv1d_x3_layout(T, Cin, 1, terms, &offW, &total, &sl);
+  return total <= 160 * 1024;
+}
+
+hipError_t launch_conv1d_x3(const float* x, int64_t sb, const void* wx, const float* bias, float* z, int B, int Cin, int Cout, int T,
+                            int terms, hipStream_t s, int mode, const AugCfg* aug) {
+  Conv1dX3Args a{};
+  if (aug && aug->on) a.aug = *aug;
+  a.x = x; a.sb = sb; a.w = (const uint4*)wx; a.bias = bias; a.z = z; a.T = T; a.Cin = Cin; a.Cout = Cout;
+  a.NT = (T + 31) / 32; a.nks = cnn1d_x3_nks(Cin);
+  const int mt = conv1d_x3_mt(T, Cin, Cout, terms, mode);
+  int total;
+  conv1d_x3_layout(T, Cin, mt, terms, &a.offW, &total, &a.slab_floats);
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(B, Cout / (32 * mt)), dim3(c1x::NTH), total, s, a);
+    return hipGetLastError();
+  };
+  if (a.aug.on) {                 // layer 1 only (one channel tile)
+    if (mt != 1) return hipErrorInvalidValue;
+    return terms == 3 ? go(conv1d_x3_kernel<1, 3, true>) : go(conv1d_x3_kernel<1, 2, true>);
+  }
+  if (terms == 3) return mt == 2 ? go(conv1d_x3_kernel<2, 3>) : go(conv1d_x3_kernel<1, 3>);
+  return mt == 2 ? go(conv1d_x3_kernel<2, 2>) : go(conv1d_x3_kernel<1, 2>);
+}
+
 bool cnn1d_fused_x3_supports(const void* x, int64_t sb, int64_t st, int64_t sf, int T, int F) {
   // (a slab of 16 channels = 4 T float4 must fit the 3 x 512 loads of a trip: T <= 384)
   if (T < 3 || T > 384 || (T + 31) / 32 > c1x::NW * c1x::MAXT1 || F < 1 || (F & 3)) return false;

@@ -69,6 +69,8 @@ struct Cnn1dState {
   // train mode: data-gradient weight images of conv layers 2 and 3 (+ a zero bias), dropout state
   void* train_packed = nullptr;
   float *wt[2] = {nullptr, nullptr}, *zero_bias = nullptr;
+  int wx3_F = 0, train_x3 = 0;
+  void* wx3[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // per-step bf16x3 A-fragment images: forward layers 1-3, data gradients 3->2, 2->1 (conv1d_x3_kernel)
   DropCfg train_drop{};
   int train_B = 0, train_T = 0;
   AugCfg aug_armed{};   // dfa_cnn1d_set_train_augment: consumed by the next forward_train
@@ -111,6 +113,9 @@ struct dfa_ctx {
   int cae_enc1_mfma = 1;       // auto-encoder eval forward, bf16 mode: block 1 on the matrix cores (cae_enc1_mfma.hip); 0 = the vector-ALU kernel
   int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
+  int cnn1d_train_x3 = 1;      // CNN1D training convolutions (3 forward, 2 data gradients) on the matrix-core layer kernel (conv1d_x3_kernel) where
+                               // its layout rules hold: 1 = three bf16 terms per operand (fp32-grade), 3 = two terms (bf16x3, ~1e-5: opt-in),
+                               // 0 = the fp32 VALU kernel (conv1d.hip); 2 = diagnostic: as 1 with one channel tile per workgroup
   int cnn1d_fused = 1;         // CNN1D eval forward as ONE kernel when T <= 384: 1 = split-bf16 kernel (cnn1d_fused_x3.hip) for the reference's
                                // storage layout, the exact-fp32 one (cnn1d_fused.hip) otherwise; 2 = always the exact-fp32 one; 0 = the three-launch path
   int clock_probe = 0;         // 1 = the bf16 block-3 kernel stamps its main loop (s_memtime / s_memrealtime) into clock_buf: dfa_ctx_clock_read
@@ -243,6 +248,11 @@ hipError_t launch_cm_bn_relu_meant(const float* z, const float* mean, const floa
 hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* up, float* partial, float* sums, float* dz, int B, int C,
                             int T, const DropCfg& dc, hipStream_t s);
+bool conv1d_x3_supports(const float* x, int64_t sb, int64_t sc, int64_t st, const float* z, int T, int Cin, int Cout, int terms);
+hipError_t launch_conv1d_x3(const float* x, int64_t sb, const void* wx, const float* bias, float* z, int B, int Cin, int Cout, int T,
+                            int terms, hipStream_t s, int mode = 1, const AugCfg* aug = nullptr);
+size_t conv1d_terms_pack_bytes(int cin, int cout, int terms);
+hipError_t launch_pack_conv1d_terms(const float* wf, void* wx, int cin, int cout, int terms, hipStream_t s);
 hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
                                float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s, const AugCfg* aug = nullptr);
 hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias, int cin, int cout, hipStream_t s);

@@ -482,10 +482,27 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     m.wt[1] = (float*)(b + al((size_t)64 * 32 * 3 * 4));
     m.zero_bias = (float*)(b + al((size_t)64 * 32 * 3 * 4) + al((size_t)128 * 64 * 3 * 4));
   }
+  // bf16x3 A-fragment images of this step's weights (they change every step): forward layers 1-3, data gradients 3->2, 2->1
+  const int xcin[5] = {F, 32, 64, 128, 64}, xcout[5] = {32, 64, 128, 64, 32};
+  if (!m.wx3[0] || m.wx3_F != F) {
+    if (m.wx3[0]) { DFA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); DFA_HIP_CHECK(ctx, hipFree(m.wx3[0])); m.wx3[0] = nullptr; }
+    size_t off[6] = {0};
+    for (int i = 0; i < 5; ++i) off[i + 1] = off[i] + al(conv1d_terms_pack_bytes(xcin[i], xcout[i], 3));
+    char* base = nullptr;
+    DFA_HIP_CHECK(ctx, hipMalloc((void**)&base, off[5]));
+    for (int i = 0; i < 5; ++i) m.wx3[i] = base + off[i];
+    m.wx3_F = F;
+  }
   const float* const* p = m.p;
   hipStream_t s = ctx->stream;
   DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[6], m.wt[0], m.zero_bias, 32, 64, s));
   DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[12], m.wt[1], m.zero_bias, 64, 128, s));
+  const int x3 = ctx->cnn1d_train_x3, terms = (x3 == 3) ? 2 : 3;
+  if (x3) {
+    const float* wsrc[5] = {p[0], p[6], p[12], m.wt[1], m.wt[0]};
+    for (int i = 0; i < 5; ++i) DFA_HIP_CHECK(ctx, launch_pack_conv1d_terms(wsrc[i], m.wx3[i], xcin[i], xcout[i], terms, s));
+  }
+  m.train_x3 = x3;
   DropCfg dc{};
   dc.thresh = (p_drop > 0.f) ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
   dc.scale = 1.0f / (1.0f - p_drop);
@@ -499,10 +516,16 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     float* z = (float*)(ws + pl.z[l]);
     const float* const* q = p + 6 * l;
     if (l == 0) {
-      DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, q[0], q[1], z, B, F, 32, T, false, s, false, aug));
+      if (x3 && conv1d_x3_supports((const float*)x, stride_b, stride_f, stride_t, z, T, F, 32, terms))
+        DFA_HIP_CHECK(ctx, launch_conv1d_x3((const float*)x, stride_b, m.wx3[0], q[1], z, B, F, 32, T, terms, s, x3, aug));
+      else
+        DFA_HIP_CHECK(ctx, launch_conv1d((const float*)x, stride_b, stride_f, stride_t, q[0], q[1], z, B, F, 32, T, false, s, false, aug));
     } else {
       const float* hin = (const float*)(ws + pl.h[l - 1]);
-      DFA_HIP_CHECK(ctx, launch_conv1d(hin, (int64_t)Cin[l] * T, T, 1, q[0], q[1], z, B, Cin[l], C[l], T, false, s, false));
+      if (x3 && conv1d_x3_supports(hin, (int64_t)Cin[l] * T, T, 1, z, T, Cin[l], C[l], terms))
+        DFA_HIP_CHECK(ctx, launch_conv1d_x3(hin, (int64_t)Cin[l] * T, m.wx3[l], q[1], z, B, Cin[l], C[l], T, terms, s, x3));
+      else
+        DFA_HIP_CHECK(ctx, launch_conv1d(hin, (int64_t)Cin[l] * T, T, 1, q[0], q[1], z, B, Cin[l], C[l], T, false, s, false));
     }
     St st = st1d(ws, pl, l);
     DFA_HIP_CHECK(ctx, launch_cm_stats(z, partial, B, C[l], T, s));
@@ -560,8 +583,12 @@ int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
       DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)(ws + pl.h[l - 1]), (int64_t)Cin[l] * T, T, 1, partial, grads[4 * l],
                                              grads[4 * l + 1], B, Cin[l], C[l], T, s));
       // data gradient: dh[l-1] = conv1d(dz; W'[Cin][Cout][3]) -- a Conv1d with Cout input channels, Cin output channels
-      DFA_HIP_CHECK(ctx, launch_conv1d(dz, (int64_t)C[l] * T, T, 1, m.wt[l - 1], m.zero_bias, (float*)(ws + pl.dh[l - 1]), B, C[l], Cin[l], T,
-                                       false, s, false));
+      float* dh = (float*)(ws + pl.dh[l - 1]);
+      const int terms = (m.train_x3 == 3) ? 2 : 3;
+      if (m.train_x3 && conv1d_x3_supports(dz, (int64_t)C[l] * T, T, 1, dh, T, C[l], Cin[l], terms))
+        DFA_HIP_CHECK(ctx, launch_conv1d_x3(dz, (int64_t)C[l] * T, m.wx3[l == 2 ? 3 : 4], m.zero_bias, dh, B, C[l], Cin[l], T, terms, s, m.train_x3));
+      else
+        DFA_HIP_CHECK(ctx, launch_conv1d(dz, (int64_t)C[l] * T, T, 1, m.wt[l - 1], m.zero_bias, dh, B, C[l], Cin[l], T, false, s, false));
     }
   }
   DFA_HIP_CHECK(ctx, hipGetLastError());

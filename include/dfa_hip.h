@@ -99,6 +99,12 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   per product (fp32-grade: logits within 1e-4 of the reference) when x is the reference's contiguous [B,F,T]
  *                   storage, the exact-fp32 matrix-core kernel for any other strides; 2 = always the exact-fp32 kernel; 0 = the
  *                   three-launch path
+ *   "cnn1d_train_x3" 1 (default) = the five convolutions of a CNN1D training step (3 forward, 2 data gradients) on the matrix cores
+ *                   (conv1d_x3_kernel) when the tensors are in the stored [B,F,T] layout, T <= 384, F % 4 == 0: every fp32 operand
+ *                   as three bf16 terms (its 24-bit mantissa exactly), six MFMAs per product -- sums of fp32 grade; a folded
+ *                   augmentation (dfa_cnn1d_set_train_augment) is applied as the input slabs are staged.  3 = two terms, three
+ *                   MFMAs (bf16x3, ~1e-5 per product: gradients then carry ReLU-flip noise of ~3e-3 relative L2; opt-in);
+ *                   0 = the fp32 vector-ALU kernels; 2 = diagnostic (as 1, one channel tile per workgroup)
  *   "clock_probe"   1 = the dominant kernel of the bf16 eval forward (CNN2D block 3) brackets its main loop with s_memtime /
  *                   s_memrealtime stamps (lane 0 of the first 1024 workgroups, into a buffer no kernel reads); dfa_ctx_clock_read
  *                   returns the shader clock the chip held inside that kernel.  0 (default) = two scalar compares per workgroup

@@ -133,3 +133,41 @@ def test_cnn1d_fused_is_one_launch_and_batch_independent(golden):
     assert counts == [1, 0, 0, 0], counts
     for i in (0, 3, 6):
         assert torch.equal(model(x[i:i + 1]), full[i:i + 1])
+
+
+@pytest.mark.parametrize("B,T,F", [(3, 321, 180), (2, 64, 180), (4, 100, 44), (2, 384, 180)])
+def test_cnn1d_training_convolutions_on_matrix_cores_match_vector_twin(B, T, F):
+    """Round 3: the five convolutions of a CNN1D training step (3 forward, 2 data gradients; src/train.py:71-76 through
+    src/model_cnn1d.py:17-34) run on `conv1d_x3_kernel` (csrc/cnn1d_fused_x3.hip) when the tensors are in the stored layout:
+    context option cnn1d_train_x3 = 1 -- every fp32 operand as three bf16 terms (its 24-bit mantissa exactly), six MFMAs per
+    product -- must reproduce the fp32 VALU kernels (option 0) to fp32 rounding: logits 1e-6, gradients 1e-5 of their scale.
+    Option 3 (two terms, bf16x3) is the opt-in fast form: logits within 1e-4, gradients limited by ReLU flips (a 1e-5
+    perturbation flips ~1e-5 of the masks; relative L2 ~ 3e-3 .. 1e-2 at these batch sizes)."""
+    from dfa_amd import _lib
+    from dfa_amd.model_cnn1d import CNN1D
+    g = torch.Generator().manual_seed(B * 1000 + T + F)
+    x = (torch.randn(B, F, T, generator=g) * 3.2).to("cuda").transpose(1, 2)
+    y = (torch.rand(B, generator=g) > 0.5).float().to("cuda")
+    ctx = _lib.Context.get(x.device)
+    res = {}
+    try:
+        for arm in (0, 1, 2, 3):
+            ctx.set_option("cnn1d_train_x3", arm)
+            torch.manual_seed(0)
+            m = CNN1D(in_features=F, dropout=0.0).to("cuda").train()
+            logits = m(x).squeeze(-1)
+            torch.nn.BCEWithLogitsLoss()(logits, y).backward()
+            res[arm] = (logits.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        ctx.set_option("cnn1d_train_x3", 1)
+    l0, g0 = res[0]
+    wscale = {"conv.0.bias": "conv.0.weight", "conv.4.bias": "conv.4.weight", "conv.8.bias": "conv.8.weight"}   # conv biases in front of a BatchNorm: gradient = 0 up to rounding
+    for arm, ltol, gtol in ((1, 2e-6, 1e-5), (2, 2e-6, 1e-5), (3, 1e-4, 5e-2)):
+        l, gr = res[arm]
+        assert float((l - l0).abs().max()) <= ltol * max(1.0, float(l0.abs().max())), (arm, float((l - l0).abs().max()))
+        for n in g0:
+            scale = float(g0[wscale.get(n, n)].abs().max())
+            assert float((gr[n] - g0[n]).abs().max()) <= gtol * scale + 1e-12, (arm, n, float((gr[n] - g0[n]).abs().max()) / scale)
+    assert torch.equal(res[1][0], res[2][0])        # one or two channel tiles per workgroup: the same sums
+    for n in g0:
+        assert torch.equal(res[1][1][n], res[2][1][n]), n
