@@ -266,9 +266,13 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     DFA_HIP_CHECK(ctx, launch_convt_w_to_q(q[0], wq, Cin, Cout, s));
     // data gradient: dX[P x Cin] = Zp[P x 4Cout] . Wq^T
     float* xf = (float*)(ws + pl.xf);
-    DFA_HIP_CHECK(ctx, launch_gemm_f32(bf, ws + pl.zp, 4 * Cout, 1, 0, wq, 1, 4 * Cout, xf, (int)P, Cin, 4 * Cout, 1, s));
     void* dx = (l == 0) ? ws + pl.de[3] : ws + pl.dd[l - 1];
-    DFA_HIP_CHECK(ctx, launch_cast_from_f32(prec, xf, dx, (size_t)P * Cin, s));
+    if (bf && ctx->cae_dgrad_mfma && convt_dgrad_bf16_supports(Cin, Cout)) {   // bf16 matrix cores, bf16 result in place
+      DFA_HIP_CHECK(ctx, launch_convt_dgrad_bf16(ws + pl.zp, wq, xf, dx, P, Cin, Cout, s));   // (xf: scratch for the bf16 weight fragments)
+    } else {
+      DFA_HIP_CHECK(ctx, launch_gemm_f32(bf, ws + pl.zp, 4 * Cout, 1, 0, wq, 1, 4 * Cout, xf, (int)P, Cin, 4 * Cout, 1, s));
+      DFA_HIP_CHECK(ctx, launch_cast_from_f32(prec, xf, dx, (size_t)P * Cin, s));
+    }
     // weight gradient: dWq[Cin x 4Cout] = X^T . Zp   (K = P, split over workgroups)
     const void* xin = (l == 0) ? ws + pl.e[3] : ws + pl.d[l - 1];
     float* dwq = (float*)(ws + pl.dwq);

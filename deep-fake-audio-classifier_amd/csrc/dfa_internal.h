@@ -112,6 +112,8 @@ struct dfa_ctx {
   int dgrad_m16 = 1;           // bf16 training: data-gradient convolutions on the 16x16x32 kernel (conv_split.hip), one launch each; 0 = the 32x32x16 kernels
   int cae_enc1_mfma = 1;       // auto-encoder eval forward, bf16 mode: block 1 on the matrix cores (cae_enc1_mfma.hip); 0 = the vector-ALU kernel
   int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
+  int cae_dgrad_mfma = 1;      // auto-encoder training, bf16 mode: ConvTranspose2d data gradients on the bf16 matrix cores writing bf16
+                               // (convt_dgrad_bf16.hip); 0 = the fp32-MFMA GEMM + cast pass of round 2
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_train_x3 = 1;      // CNN1D training convolutions (3 forward, 2 data gradients) on the matrix-core layer kernel (conv1d_x3_kernel) where
                                // its layout rules hold: 1 = three bf16 terms per operand (fp32-grade), 3 = two terms (bf16x3, ~1e-5: opt-in),
@@ -328,6 +330,8 @@ hipError_t launch_cae_dec4_bwd(int prec, const void* d3, const float* w4, const 
 constexpr int kMseBlocks = 1024;
 hipError_t launch_mse_fwd_bwd(const float* recon, const void* x, int x_bf16, int64_t sb, int64_t st, int64_t sf, int B, int T, int F,
                               float* partial, float* loss, float* drecon, hipStream_t s);
+bool convt_dgrad_bf16_supports(int Cin, int Cout);
+hipError_t launch_convt_dgrad_bf16(const void* zp, const float* wq, void* wfrag, void* dx, long P, int Cin, int Cout, hipStream_t s);
 hipError_t launch_cast_from_f32(int prec, const float* src, void* dst, size_t n, hipStream_t s);
 hipError_t launch_reduce_wgrad_window(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
                                       int ci_off, int co_off, float* dw, hipStream_t s);

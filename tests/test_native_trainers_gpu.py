@@ -154,3 +154,46 @@ def test_flat_trainer_bridge_writes_gradients_straight_into_the_flat_buffer(gold
     r3, _ = m(x)
     torch.nn.MSELoss()(r3, x).backward()
     assert first.grad is not None and torch.isfinite(first.grad).all()
+
+
+@pytest.mark.parametrize("B,T", [(3, 96), (2, 321)])
+def test_cae_convtranspose_data_gradient_on_bf16_matrix_cores_matches_fp32_gemm(B, T):
+    """Round 3: in bf16 mode the three ConvTranspose2d data gradients of the auto-encoder's backward (autograd of
+    src/model_cae.py:63-79 inside loss.backward(), src/train_cae.py:71) run on `convt_dgrad_bf16_kernel` (bf16 weights -- the
+    ones the forward multiplied by -- fp32 accumulation, bf16 result in place) instead of an fp32-MFMA GEMM + cast pass (context
+    option cae_dgrad_mfma = 0).  Same forward, so the loss is identical; the gradients differ by the rounding of W in the
+    backward (2^-9 per weight) and what seven BatchNorm + ReLU layers make of it: every gradient within 3 % relative L2 (the
+    bound the emulated-oracle test gives decoder gradients), the decoder's last block -- upstream of every changed kernel --
+    bit-identical."""
+    from dfa_amd import _lib
+    from dfa_amd.model_cae import ConvAutoencoder
+    g = torch.Generator().manual_seed(B * 7 + T)
+    x = torch.randn(B, T, 180, generator=g).to("cuda", torch.bfloat16)
+    ctx = _lib.Context.get(x.device)
+    res = {}
+    try:
+        for arm in (0, 1):
+            ctx.set_option("cae_dgrad_mfma", arm)
+            torch.manual_seed(0)
+            m = ConvAutoencoder(precision="bf16").to("cuda").train()
+            recon, _ = m(x)
+            loss = torch.nn.functional.mse_loss(recon, x.float())
+            loss.backward()
+            res[arm] = (float(loss), {n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        ctx.set_option("cae_dgrad_mfma", 1)
+    assert res[0][0] == res[1][0]
+    worst = 0.0
+    for n, g0 in res[0][1].items():
+        g1 = res[1][1][n]
+        assert torch.isfinite(g1).all(), n
+        rel = float((g1 - g0).norm() / (g0.norm() + 1e-30))
+        if n.startswith("decoder.9") or n.startswith("decoder.10"):      # ConvTranspose2d(32 -> 1) (+ nothing behind it): untouched
+            assert torch.equal(g0, g1), n
+        if n.endswith(".bias") and n[:-5] + ".weight" in res[0][1] and res[0][1][n[:-5] + ".weight"].dim() == 4 and not n.startswith("decoder.9"):
+            # a convolution bias in front of a BatchNorm: its gradient is zero up to rounding -- compare on the weight gradient's scale
+            assert float((g1 - g0).abs().max()) <= 1e-2 * float(res[0][1][n[:-5] + ".weight"].abs().max()), n   # (bf16 storage noise of dz)
+            continue
+        assert rel <= 3e-2, (n, rel)
+        worst = max(worst, rel)
+    print(f"cae dgrad on bf16 matrix cores vs fp32 GEMM [{B},{T},180]: worst relative L2 over 30 gradients {worst:.2e}")
