@@ -183,13 +183,26 @@ __global__ __launch_bounds__(256) void cl_stats_kernel(const T* __restrict__ z, 
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (pl < PL)
-    for (size_t p = p0 + pl; p < p1; p += PL) {
+  if (pl < PL) {
+    // four pixels per trip: four independent 16-byte loads in flight per lane (one at a time left this pass at 0.8 TB/s: a
+    // 4096-pixel block per workgroup gave 55-900 workgroups of serial single loads)
+    size_t p = p0 + pl;
+    for (; p + 3 * (size_t)PL < p1; p += 4 * (size_t)PL) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ld8<T>(z + (p + u * (size_t)PL) * C + cg * 8, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += v[u][j]; s2[j] = fmaf(v[u][j], v[u][j], s2[j]); }
+    }
+    for (; p < p1; p += PL) {
       float v[8];
       ld8<T>(z + p * C + cg * 8, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
     }
+  }
   if (pl < PL) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[(pl * C + cg * 8 + j) * 2] = s1[j]; red[(pl * C + cg * 8 + j) * 2 + 1] = s2[j]; }
@@ -740,8 +753,8 @@ hipError_t launch_bn_relu_pool_drop(int prec, const void* z, const float* mean, 
 }
 
 int cl_stats_blocks(size_t npix, int* pix_per_block) {
-  *pix_per_block = 4096;
-  return (int)((npix + 4095) / 4096);
+  *pix_per_block = 1024;
+  return (int)((npix + 1023) / 1024);
 }
 
 hipError_t launch_cl_stats(int prec, const void* z, float* partial, size_t npix, int C, hipStream_t s) {
