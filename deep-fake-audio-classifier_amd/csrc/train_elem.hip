@@ -445,13 +445,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     s1[j] = 0.f; s2[j] = 0.f;
   }
   const float inv_h = 1.0f / (float)H;
-  for (size_t p = p0 + pl; p < p1; p += PL) {
-    const int f = (int)(p % W);
-    const size_t bt_ = p / W;
-    const int t = (int)(bt_ % H), b = (int)(bt_ / H);
-    float v[8], g[8];
-    ld8<T>(z + p * C + cg * 8, v);
-    upstream8<T, SRC>(demb, da, dc, b, t, f, cg, H, W, C, inv_h, g);
+  // Pixel index arithmetic in 32 bits (npix < 2^31, launcher-checked: the 64-bit divisions by W and H cost more than the rest of
+  // the loop body) and four pixels per trip, all eight loads requested before the first is used (one dependent pair at a time
+  // held this pass at ~1 TB/s)
+  auto body = [&](const float (&v)[8], const float (&g)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (v[j] - mu[j]) * is[j];
@@ -459,6 +456,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       s1[j] += dy;
       s2[j] = fmaf(dy, xh, s2[j]);
     }
+  };
+  auto fetch = [&](unsigned p, float (&v)[8], float (&g)[8]) {
+    const unsigned f = p % (unsigned)W, bt_ = p / (unsigned)W;
+    const unsigned t = bt_ % (unsigned)H, b = bt_ / (unsigned)H;
+    ld8<T>(z + (size_t)p * C + cg * 8, v);
+    upstream8<T, SRC>(demb, da, dc, (int)b, (int)t, (int)f, cg, H, W, C, inv_h, g);
+  };
+  unsigned p = (unsigned)p0 + pl;
+  const unsigned pe = (unsigned)p1;
+  for (; p + 3u * PL < pe; p += 4u * PL) {
+    float v[4][8], g[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch(p + u * PL, v[u], g[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(v[u], g[u]);
+  }
+  for (; p < pe; p += PL) {
+    float v[8], g[8];
+    fetch(p, v, g);
+    body(v, g);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[(pl * C + cg * 8 + j) * 2] = s1[j]; red[(pl * C + cg * 8 + j) * 2 + 1] = s2[j]; }
@@ -496,12 +513,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
   const float inv_h = 1.0f / (float)H;
 #pragma unroll 4
-  for (size_t p = p0 + pl; p < p1; p += PL) {
-    const int f = (int)(p % W);
-    const size_t bt_ = p / W;
-    const int t = (int)(bt_ % H), b = (int)(bt_ / H);
+  for (unsigned p = (unsigned)p0 + pl; p < (unsigned)p1; p += PL) {          // (32-bit pixel arithmetic, see the reduce kernel)
+    const int f = (int)(p % (unsigned)W);
+    const unsigned bt_ = p / (unsigned)W;
+    const int t = (int)(bt_ % (unsigned)H), b = (int)(bt_ / (unsigned)H);
     float v[8], g[8], o[8];
-    ld8<T>(z + p * C + cg * 8, v);
+    ld8<T>(z + (size_t)p * C + cg * 8, v);
     upstream8<T, SRC>(demb, da, dc, b, t, f, cg, H, W, C, inv_h, g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -509,7 +526,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       const float dy = (fmaf(gm[j], xh, bt[j]) > 0.f) ? g[j] : 0.f;
       o[j] = k0[j] * (dy - k1[j] - xh * k2[j]);
     }
-    st8<T>(dz + p * C + cg * 8, o);
+    st8<T>(dz + (size_t)p * C + cg * 8, o);
   }
 }
 
@@ -840,7 +857,12 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
                          int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch) {
   int ppb;
-  const int nblk = bn_bwd_blocks(B, H, W, &ppb);
+  int nblk = bn_bwd_blocks(B, H, W, &ppb);
+  if ((size_t)B * H * W >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit pixel indices in the generic kernels
+  if (src == SRC_DIRECT || src == SRC_POOL22) {   // the auto-encoder's layers (55-900 blocks of 4096 pixels did not fill the chip)
+    ppb = 1024;
+    nblk = (int)(((size_t)B * H * W + ppb - 1) / ppb);
+  }
   const int PL = 256 / (C / 8);
   const size_t lds = (size_t)PL * C * 2 * sizeof(float);
   const int ppb2 = 16 * PL;                       // pixels per block of the apply pass: 16 chunks per thread
