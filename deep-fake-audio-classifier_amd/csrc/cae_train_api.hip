@@ -232,6 +232,9 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
   float* partial = (float*)(ws + pl.partial);
   float* rec = (float*)(ws + pl.rec);
   float* scratch_c = (float*)(ws + pl.sums) + 2 * 704;   // 1024 floats of scratch behind the sums block
+  // second-level scratch of the block-record reductions (64 x C x 2 floats): the upper half of the partial buffer -- the records
+  // of the BatchNorm / statistics passes (<= 3600 x 512 floats) use a fraction of the lower half (sized for the weight gradients)
+  float* scratch2 = partial + pl.partial_bytes / 8;
   const int bf = (prec == DFA_PREC_BF16) ? 1 : 0;
   DropCfg nodrop{};
   // ---- decoder block 4
@@ -251,14 +254,14 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     St st = stat_of(ws, pl, 4 + l, Cout);
     float* sm = sums_of(ws, pl, 4 + l);
     DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_DIRECT, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], nullptr, ws + pl.dd[l], partial, sm,
-                                     ws + pl.dzd[l], B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s));
+                                     ws + pl.dzd[l], B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s, scratch2));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[16 + 4 * l + 2], grads[16 + 4 * l + 3], Cout);
     {  // ConvTranspose2d bias gradient = channel sums of dz over ALL output pixels (the output_padding column included)
       int ppb;
       const size_t npix = (size_t)B * pl.Hd[l] * pl.Wd[l];
       const int nblk = cl_stats_blocks(npix, &ppb);
       DFA_HIP_CHECK(ctx, launch_cl_stats(prec, ws + pl.dzd[l], partial, npix, Cout, s));
-      DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nblk, Cout * 2, 1.0f, scratch_c, s, nullptr));
+      DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nblk, Cout * 2, 1.0f, scratch_c, s, scratch2));
       hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, scratch_c, scratch_c + 512, grads[16 + 4 * l + 1], Cout);
     }
     DFA_HIP_CHECK(ctx, launch_pixel_unshuffle(prec, ws + pl.dzd[l], ws + pl.zp, B, Hin, Win, pl.Wd[l], Cout, s));
@@ -290,7 +293,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     St st = stat_of(ws, pl, l, kEC[l]);
     float* sm = sums_of(ws, pl, l);
     DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL22, ws + pl.z[l], st.mean, st.invstd, p[6 * l + 2], p[6 * l + 3], nullptr, ws + pl.de[l], partial, sm,
-                                     ws + pl.dz[l], B, pl.H[l], pl.W[l], kEC[l], nodrop, s));
+                                     ws + pl.dz[l], B, pl.H[l], pl.W[l], kEC[l], nodrop, s, scratch2));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], kEC[l]);
     if (l == 3) {
       for (int co = 0; co < 2; ++co)
