@@ -578,10 +578,10 @@ int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], C[l]);
     if (l == 0) {
       DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)x, stride_b, stride_f, stride_t, partial, grads[0], grads[1], B, F, 32, T, s,
-                                             m.train_aug.on ? &m.train_aug : nullptr));
+                                             m.train_aug.on ? &m.train_aug : nullptr, m.train_x3));
     } else {
       DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)(ws + pl.h[l - 1]), (int64_t)Cin[l] * T, T, 1, partial, grads[4 * l],
-                                             grads[4 * l + 1], B, Cin[l], C[l], T, s));
+                                             grads[4 * l + 1], B, Cin[l], C[l], T, s, nullptr, m.train_x3));
       // data gradient: dh[l-1] = conv1d(dz; W'[Cin][Cout][3]) -- a Conv1d with Cout input channels, Cin output channels
       float* dh = (float*)(ws + pl.dh[l - 1]);
       const int terms = (m.train_x3 == 3) ? 2 : 3;

@@ -238,6 +238,121 @@ __global__ __launch_bounds__(64) void conv1d_wgrad_mfma_kernel(const float* __re
   if (blockIdx.y == 0 && hh == 0) rec[(size_t)Cout * Cin * 3 + o0 + r] = ab;
 }
 
+// ---- the same weight gradient on the bf16 matrix cores at fp32 grade: every fp32 operand is carried as three bf16 terms
+// (hi + lo + lo2 = its 24-bit mantissa exactly) and every product is six v_mfma_f32_32x32x16_bf16 (all term pairs of order <= 2),
+// as the training convolutions of cnn1d_fused_x3.hip do.  The fp32 matrix pipe issues one 32x32x2 MFMA per ~80 cycles: 24 of them
+// per 16 frames and tap triple = 1920 cycles; the same products cost 18 x 32 = 576 matrix-pipe cycles here plus the splits.
+// Same decomposition and slab pipeline as the kernel above; the LDS tiles are laid out for aligned 16-byte fragment reads (row
+// pitch 68 floats: the 16 lanes of a ds_read_b128 group fall on distinct banks): a lane reads its row's 8 dz frames (two reads)
+// and 12 h frames (three reads: frames t-1 .. t+10) per 16-frame k-step, the three taps are register windows [k, k + 8) of
+// those 12 values.
+__device__ __forceinline__ void w1d_split3(const float (&v)[8], uint4 (&f)[3]) {
+  unsigned q[3][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float r0 = v[2 * p], r1 = v[2 * p + 1];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      q[t][p] = pack_bf16x2(r0, r1);
+      if (t < 2) { r0 -= __uint_as_float(q[t][p] << 16); r1 -= __uint_as_float(q[t][p] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) f[t] = make_uint4(q[t][0], q[t][1], q[t][2], q[t][3]);
+}
+__device__ __forceinline__ f32x16_t w1d_mma(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <bool AUG>
+__global__ __launch_bounds__(64) void conv1d_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ h,
+                                                             int64_t hsb, int64_t hsc, int64_t hst,
+                                                             float* __restrict__ partial, int B, int Cin, int Cout, int T,
+                                                             int bchunk, AugCfg aug) {
+  constexpr int PITCH = 68;
+  __shared__ __attribute__((aligned(16))) float dzs[32][PITCH];
+  __shared__ __attribute__((aligned(16))) float hs[32][PITCH];      // hs[c][i] = frame t0 - 1 + i, i < 66 (67 = zero)
+  const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+  const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32, ch = blockIdx.z;
+  const int b0 = ch * bchunk, b1 = min(B, b0 + bchunk);
+  f32x16_t acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  float ab = 0.f;
+  const int nslab_t = (T + W1D_TT - 1) / W1D_TT;
+  const int nslab = (b1 - b0) * nslab_t;
+  float rdz[32], rh[32], rh2 = 0.f;
+  auto fetch = [&](int sl) {
+    const int b = b0 + sl / nslab_t, t0 = (sl % nslab_t) * W1D_TT;
+#pragma unroll
+    for (int oo = 0; oo < 32; ++oo)
+      rdz[oo] = (t0 + lane < T) ? dz[((size_t)b * Cout + o0 + oo) * T + t0 + lane] : 0.f;
+    const int t = t0 - 1 + lane;
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) {
+      const int ci = c0 + cc;
+      if constexpr (AUG)
+        rh[cc] = (ci < Cin && t >= 0 && t < T) ? aug_apply(aug, h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)aug_src_t(aug, t) * hst], b, t, ci) : 0.f;
+      else
+        rh[cc] = (ci < Cin && t >= 0 && t < T) ? h[(int64_t)b * hsb + (int64_t)ci * hsc + (int64_t)t * hst] : 0.f;
+    }
+    const int ci2 = c0 + (lane & 31), t2 = t0 + 63 + (lane >> 5);
+    if constexpr (AUG)
+      rh2 = (ci2 < Cin && t2 < T) ? aug_apply(aug, h[(int64_t)b * hsb + (int64_t)ci2 * hsc + (int64_t)aug_src_t(aug, t2) * hst], b, t2, ci2) : 0.f;
+    else
+      rh2 = (ci2 < Cin && t2 < T) ? h[(int64_t)b * hsb + (int64_t)ci2 * hsc + (int64_t)t2 * hst] : 0.f;
+  };
+  if (lane < 32) { hs[lane][66] = 0.f; hs[lane][67] = 0.f; }      // the tail of the 12-frame window of the last k-step
+  if (nslab > 0) fetch(0);
+  for (int sl = 0; sl < nslab; ++sl) {
+    __syncthreads();
+#pragma unroll
+    for (int oo = 0; oo < 32; ++oo) dzs[oo][lane] = rdz[oo];
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) hs[cc][lane] = rh[cc];
+    hs[lane & 31][64 + (lane >> 5)] = rh2;
+    __syncthreads();
+    if (sl + 1 < nslab) fetch(sl + 1);
+#pragma unroll
+    for (int ks = 0; ks < W1D_TT / 16; ++ks) {
+      float dv[8], hv[12];
+      *(float4*)&dv[0] = *(const float4*)&dzs[r][16 * ks + 8 * hh];
+      *(float4*)&dv[4] = *(const float4*)&dzs[r][16 * ks + 8 * hh + 4];
+      *(float4*)&hv[0] = *(const float4*)&hs[r][16 * ks + 8 * hh];
+      *(float4*)&hv[4] = *(const float4*)&hs[r][16 * ks + 8 * hh + 4];
+      *(float4*)&hv[8] = *(const float4*)&hs[r][16 * ks + 8 * hh + 8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ab += dv[j];
+      uint4 a[3];
+      w1d_split3(dv, a);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float win[8] = {hv[k], hv[k + 1], hv[k + 2], hv[k + 3], hv[k + 4], hv[k + 5], hv[k + 6], hv[k + 7]};
+        uint4 bq[3];
+        w1d_split3(win, bq);
+        acc[k] = w1d_mma(a[2], bq[0], acc[k]);          // smallest terms first
+        acc[k] = w1d_mma(a[0], bq[2], acc[k]);
+        acc[k] = w1d_mma(a[1], bq[1], acc[k]);
+        acc[k] = w1d_mma(a[1], bq[0], acc[k]);
+        acc[k] = w1d_mma(a[0], bq[1], acc[k]);
+        acc[k] = w1d_mma(a[0], bq[0], acc[k]);
+      }
+    }
+  }
+  float* rec = partial + (size_t)ch * ((size_t)Cout * Cin * 3 + Cout);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = o0 + (i & 3) + 8 * (i >> 2) + 4 * hh, c = c0 + r;
+      if (c < Cin) rec[((size_t)o * Cin + c) * 3 + k] = acc[k][i];
+    }
+  ab += __shfl_xor(ab, 32, 64);
+  if (blockIdx.y == 0 && hh == 0) rec[(size_t)Cout * Cin * 3 + o0 + r] = ab;
+}
+
 // data-gradient weights of Conv1d: W'[c][o][k'] = W[o][c][2-k']  (a Conv1d with Cin' = Cout, Cout' = Cin)
 __global__ void conv1d_dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, float* __restrict__ zero_bias,
                                          int cin, int cout) {
@@ -313,9 +428,15 @@ hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const fl
 // partial: conv1d_wgrad_chunks(B) * (Cout*Cin*3 + Cout) floats
 int conv1d_wgrad_chunks(int B) { return B < 256 ? B : 256; }
 hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
-                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s, const AugCfg* aug) {
+                               float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s, const AugCfg* aug, int x3) {
   const int nch = conv1d_wgrad_chunks(B), bchunk = (B + nch - 1) / nch;
-  if (aug && aug->on) {
+  if (x3 && Cout % 32 == 0) {      // three-term bf16 matrix-core form (fp32-grade sums)
+    const dim3 grid(Cout / 32, (Cin + 31) / 32, nch);
+    if (aug && aug->on)
+      hipLaunchKernelGGL(conv1d_wgrad_x3_kernel<true>, grid, dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk, *aug);
+    else
+      hipLaunchKernelGGL(conv1d_wgrad_x3_kernel<false>, grid, dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk, AugCfg{});
+  } else if (aug && aug->on) {
     if (Cout % 32 != 0) return hipErrorInvalidValue;   // the folded form exists for the MFMA kernel only (layer 1: Cout = 32)
     hipLaunchKernelGGL(conv1d_wgrad_mfma_kernel<true>, dim3(Cout / 32, (Cin + 31) / 32, nch), dim3(64), 0, s, dz, h, hsb, hsc, hst, partial, B, Cin, Cout, T, bchunk, *aug);
   } else if (Cout % 32 == 0)
