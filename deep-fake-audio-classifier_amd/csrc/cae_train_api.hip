@@ -172,11 +172,29 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
   // ---- encoder block 1 (pre-BN output recomputed from x: statistics pass, fold, fused eval kernel)
   {
     St st = stat_of(ws, pl, 0, 32);
-    DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, nullptr, nullptr,
-                                          nullptr, nullptr, prec, partial, B, T, F, nodrop, s));
-    DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, st.mean, st.var, st.invstd, rmv(4), rmv(5), momentum, s));
+    // bf16 mode on bf16 features (F even): the statistics pass (with the 9 x 9 tap moments the fused backward algebra needs) and
+    // the backward pass on the matrix cores (train_conv1_mfma.hip, as the CNN2D's block 1), the forward on cae_enc1_mfma.hip
+    m.train_c1_mfma = (ctx->conv1_mfma && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && F <= 224 && !(F & 1) && T >= 4) ? 1 : 0;
+    if (m.train_c1_mfma) {
+      const int nbm = conv1_mfma_blocks(B, T, F);
+      DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_STATS, x, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, partial, B, T, F, nodrop, s));
+      DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nbm, 32, (double)B * T * F, st.mean, st.var, st.invstd, rmv(4), rmv(5), momentum, s));
+      float* xxs = (float*)(ws + pl.rec) + 512;           // XX[9][9] | Xs[9]: kept for the backward
+      DFA_HIP_CHECK(ctx, launch_reduce_partials(partial + (size_t)nbm * 64, nbm, 96, 1.0f, xxs, s, partial + (size_t)nbm * 160));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, nullptr, nullptr,
+                                            nullptr, nullptr, prec, partial, B, T, F, nodrop, s));
+      DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, st.mean, st.var, st.invstd, rmv(4), rmv(5), momentum, s));
+    }
     DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], st.mean, st.var, m.tw1, m.tb1, 32, s));
-    DFA_HIP_CHECK(ctx, launch_cae_enc1(x, x_dtype, stride_b, stride_t, stride_f, nullptr, nullptr, m.tw1, m.tb1, ws + pl.e[0], prec, B, T, F, s));
+    if (m.train_c1_mfma && ctx->cae_enc1_mfma) {
+      uint4* tpack = (uint4*)(ws + pl.wq);                // this step's three-term A operands (pl.wq is free until the decoder's backward)
+      float* tbias = (float*)(ws + pl.wq) + 6 * 64 * 4;
+      DFA_HIP_CHECK(ctx, launch_pack_cae_enc1_mfma(m.tw1, m.tb1, tpack, tbias, s));
+      DFA_HIP_CHECK(ctx, launch_cae_enc1_mfma(x, x_dtype, stride_b, stride_t, stride_f, nullptr, nullptr, tpack, tbias, ws + pl.e[0], B, T, F, s));
+    } else {
+      DFA_HIP_CHECK(ctx, launch_cae_enc1(x, x_dtype, stride_b, stride_t, stride_f, nullptr, nullptr, m.tw1, m.tb1, ws + pl.e[0], prec, B, T, F, s));
+    }
   }
   // ---- encoder blocks 2-4
   for (int l = 1; l < 4; ++l) {
@@ -317,6 +335,17 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     float* sm = sums_of(ws, pl, 0);
     const int nb1 = conv1_train_blocks(B, T, F);
     float* scratch = partial + (size_t)nb1 * 320;
+    if (m.train_c1_mfma && ctx->conv1_mfma) {   // one pass on the matrix cores + the fused algebra (train_conv1.hip header)
+      const int nbm = conv1_mfma_blocks(B, T, F);
+      float* xxs = (float*)(ws + pl.rec) + 512;
+      float* c1rec = (float*)(ws + pl.rec) + 640;         // [32][11]
+      DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_BWD, x, stride_b, stride_t, stride_f, m.tw1, m.tb1, nullptr, ws + pl.de[0], partial, B, T, F, nodrop, s, 2));
+      DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nbm, 352, 1.0f, c1rec, s, partial + (size_t)nbm * 352));
+      DFA_HIP_CHECK(ctx, launch_conv1_bwd_finalize(c1rec, xxs, p[0], p[1], st.mean, st.invstd, p[2], (double)B * T * F, grads[0], grads[1],
+                                                   grads[2], grads[3], s, 1));
+      DFA_HIP_CHECK(ctx, hipGetLastError());
+      return DFA_OK;
+    }
     DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], st.mean, st.invstd, p[2], p[3],
                                           nullptr, ws + pl.de[0], prec, partial, B, T, F, nodrop, s, 2));
     DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm, s, scratch));

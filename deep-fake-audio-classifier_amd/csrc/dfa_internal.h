@@ -92,6 +92,7 @@ struct CaeState {
   // train mode (cae_train_api.hip): raw forward images, data-gradient images, raw ConvTranspose2d images
   void* train_packed = nullptr;
   float *tw1 = nullptr, *tb1 = nullptr;
+  int train_c1_mfma = 0;       // this step's block-1 passes run on the matrix cores (train_conv1_mfma.hip, 2x2-pool backward)
   PackedConv tenc[3], tdg[3], tdec[3];
   int train_prec = -1, train_B = 0, train_T = 0;
 };
@@ -304,7 +305,7 @@ int conv1_train_blocks(int B, int T, int F);
 enum { C1X_STATS = 0, C1X_FWD = 1, C1X_BWD = 2 };
 int conv1_mfma_blocks(int B, int T, int F);
 hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, int64_t sf, const float* w, const float* bias,
-                             void* a1, const void* da1, float* partial, int B, int T, int F, const DropCfg& dc, hipStream_t s);
+                             void* a1, const void* da1, float* partial, int B, int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1);
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,

@@ -68,6 +68,7 @@ struct C1xArgs {
   const bf16_t* da1;    // BWD: in  [B][Ho][F][32]
   float* partial;       // STATS: [nblk][32][2] then [nblk][96];  BWD: [nblk][32][11]
   int T, F, Ho, FP, rows_per_wg;
+  int poolw;            // BWD: da1 is [B][Ho][F / poolw][32]: 1 = AvgPool2d((2,1)) (CNN2D), 2 = AvgPool2d(2) (auto-encoder block 1, F even)
   float out_scale;      // 0.5 * dropout scale: FWD folds it into the weights, BWD applies it to the sums
   DropCfg dc;
   int dbg;              // DFA_C1X_DBG (diagnostic): 1 = no tiles, 2 = no im2col, 4 = no feature-row traffic
@@ -286,12 +287,13 @@ __global__ __launch_bounds__(256, 2) void conv1_mfma_kernel(C1xArgs a) {
       } else {
         // upstream gradient of channel r at this lane's 16 pixels.  Columns beyond F are clamped to a valid address: their im2col
         // records are all zero (y = 0 -> mask off, taps = 0), whatever is read there drops out.
-        const bf16_t* drow = a.da1 + ((size_t)b * Ho + to) * F * 32 + r;
+        const int psh = a.poolw - 1;                                         // pooled column = pixel column >> psh
+        const bf16_t* drow = a.da1 + ((size_t)b * Ho + to) * (F >> psh) * 32 + r;
         unsigned dpk[8];
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
           const int p0 = min(f0 + (i & 3) + 8 * (i >> 2) + 4 * h, F - 1), p1 = min(f0 + (i & 3) + 8 * (i >> 2) + 4 * h + 1, F - 1);
-          dpk[i >> 1] = (unsigned)drow[(size_t)p0 * 32].v | ((unsigned)drow[(size_t)p1 * 32].v << 16);
+          dpk[i >> 1] = (unsigned)drow[(size_t)(p0 >> psh) * 32].v | ((unsigned)drow[(size_t)(p1 >> psh) * 32].v << 16);
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -368,15 +370,17 @@ int conv1_mfma_blocks(int B, int T, int F) {
 }
 
 hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, int64_t sf, const float* w, const float* bias,
-                             void* a1, const void* da1, float* partial, int B, int T, int F, const DropCfg& dc, hipStream_t s) {
+                             void* a1, const void* da1, float* partial, int B, int T, int F, const DropCfg& dc, hipStream_t s, int poolw) {
   C1xArgs a{};
+  if (poolw != 1 && (poolw != 2 || mode != C1X_BWD || (F & 1))) return hipErrorInvalidValue;   // the 2x2 form exists for the backward pass (STATS is pool-free)
+  a.poolw = poolw;
   a.x = (const bf16_t*)x; a.sb = sb; a.st = st; a.sf = sf;
   a.w = w; a.b = bias; a.a1 = (bf16_t*)a1; a.da1 = (const bf16_t*)da1; a.partial = partial;
   a.T = T; a.F = F; a.Ho = T / 2; a.FP = (F + 31) / 32 * 32;
   a.rows_per_wg = conv1_mfma_rows_per_wg(B, T, F);
   a.dc = dc;
   { static const char* e = getenv("DFA_C1X_DBG"); a.dbg = e ? atoi(e) : 0; }
-  a.out_scale = 0.5f * (dc.thresh != 0 ? dc.scale : 1.0f);
+  a.out_scale = (poolw == 2 ? 0.25f : 0.5f) * (dc.thresh != 0 ? dc.scale : 1.0f);
   const int np = (T + 1) / 2;
   dim3 grid((np + a.rows_per_wg - 1) / a.rows_per_wg, B), block(256);
   const size_t RS = (size_t)c1x_row_bytes(a.FP);
