@@ -80,7 +80,9 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *   "conv1_mfma"    1 (default) = bf16 training on bf16 features without a folded augmentation: the block-1 statistics,
  *                   forward and fused backward passes run on the matrix cores (train_conv1_mfma.hip); 0 = vector-ALU kernels.
  *                   May be cleared between dfa_cnn2d_forward_train and dfa_cnn2d_backward (both backward kernels read the
- *                   same forward state; used by the twin test)
+ *                   same forward state; used by the twin test).  The auto-encoder's training step (bf16 mode, bf16 features, even F)
+ *                   obeys the same option: statistics + fused backward (2 x 2-pool form) on the same kernels, forward on
+ *                   cae_enc1_mfma.hip; 0 = a statistics pass, the eval kernel and two vector-ALU backward passes
  *   "conv1_bwd_fused" 1 (default) = block-1 backward as one pass over da1 + algebra, 0 = reduce pass + weight-gradient pass
  *   "dgrad_m16"     1 (default) = bf16 training: each data-gradient convolution is ONE launch of the 16x16x32 kernel
  *                   (conv_split.hip), 0 = the 32x32x16 kernels (block 3 as two Cin-half launches through fp32 partial sums)
