@@ -468,6 +468,10 @@ def other_models_metric(torch, device, B, steps=20, warmup=5):
         out["cae_train_step_bf16"] = cae_train_metric(torch, device, B)
     except Exception as e:                                   # secondary leg: report, never lose the headline line
         out["cae_train_step_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["cnn1d_train_step"] = cnn1d_train_metric(torch, device, B)
+    except Exception as e:  # noqa: BLE001
+        out["cnn1d_train_step"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -497,6 +501,38 @@ def cae_train_metric(torch, device, B, steps=10, warmup=4):
                          "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16"], 4),
                          "flops_per_utt": CAE_TRAIN_FLOPS_PER_UTT, "traffic": traffic if B == B_PER_GPU else None,
                          "traffic_source": src}}
+
+
+def cnn1d_train_metric(torch, device, B, steps=30, warmup=6):
+    """CNN1D training step (src/train.py:71-76 with --model cnn1d: BCE on smoothed labels, backward, AdamW) on the all-C-ABI
+    trainer, fp32 features in the stored [B, F, T] layout: convolutions and weight gradients on the matrix cores with three bf16
+    terms per operand (fp32-grade sums).  Bound by HBM in SURVEY's table: x is read twice (layer-1
+    convolution, layer-1 weight gradient) and every activation / gradient tensor written once and read twice."""
+    from dfa_amd.model_cnn1d import CNN1D
+    from dfa_amd.training.train_step import NativeTrainer
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(B, F, T, generator=g) * 3.2 - 0.07).to(device).transpose(1, 2)
+    y = (torch.rand(B, generator=g) > 0.5).float().to(device)
+    tr = NativeTrainer(CNN1D(in_features=F, dropout=0.2).to(device), label_smoothing=0.05)
+    for _ in range(warmup):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # algorithmic bytes per utterance: x twice; z1..z3, h1, h2 (fp32 [C][T]) written once and read twice; dz3..dz1, dh2, dh1 likewise
+    elems = (32 + 64 + 128) + (32 + 64) + (128 + 64 + 32) + (64 + 32)
+    bytes_per_utt = 2 * F * T * 4 + 3 * elems * T * 4
+    gbs = B * bytes_per_utt / dt / 1e9
+    traffic, src = pmc_step_traffic("cnn1d_train_step")
+    return {"value": round(B / dt, 1), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 4), "loss": round(float(loss), 5),
+            "trainer": "NativeTrainer(kind='cnn1d')", "dtype": "fp32 (three bf16 terms per operand on the matrix cores)",
+            "roofline": {"bound": "hbm", "scope": "whole step, algorithmic bytes / wall time", "achieved": round(gbs, 1), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "bytes_per_utt": bytes_per_utt,
+                         "traffic": traffic if B == B_PER_GPU else None, "traffic_source": src}}
 
 
 def spawn_ranks(args):
