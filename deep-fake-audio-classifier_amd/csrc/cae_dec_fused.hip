@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a
           for (int c = 0; c < 2; ++c) xr[mt][c] = cdf_ldraw<XBF>(xu, o0 + 2u * (mt >> 1) * ust + (2u * (mt & 1) + c) * usf);
         if constexpr (NORM) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { mu4[c] = a.mu[fq + c]; sg4[c] = a.sigma[fq + c]; }
+          for (int c = 0; c < 4; ++c) { mu4[c] = a.mu[fq + c]; sg4[c] = __builtin_amdgcn_rcpf(a.sigma[fq + c]); }   // 1 / sigma (v_rcp_f32: the error term is fp32, 1-2 ulp are far below the 2e-5 score tolerance)
         }
       }
       uint4 dk[4];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a
         const float r0 = y[0] + b4, r1 = y[1] + b4;
         if (valid) {
           float x0 = xr[mt][0], x1 = xr[mt][1];
-          if constexpr (NORM) { x0 = (x0 - mu4[2 * (mt & 1)]) / sg4[2 * (mt & 1)]; x1 = (x1 - mu4[2 * (mt & 1) + 1]) / sg4[2 * (mt & 1) + 1]; }
+          if constexpr (NORM) { x0 = (x0 - mu4[2 * (mt & 1)]) * sg4[2 * (mt & 1)]; x1 = (x1 - mu4[2 * (mt & 1) + 1]) * sg4[2 * (mt & 1) + 1]; }
           const float d0 = r0 - x0, d1 = r1 - x1;
           err = fmaf(d0, d0, err);
           err = fmaf(d1, d1, err);
