@@ -40,6 +40,37 @@ class FeatureNormalizer:
         return obj
 
 
+def fit_normalizer_sharded(features: torch.Tensor, rows: torch.Tensor, rank: int = 0, world: int = 1, chunk: int = 64) -> FeatureNormalizer:
+    """FeatureNormalizer.fit (src/dataset_cae.py:24-29: mean / unbiased std over all frames of the bonafide utterances, per
+    feature dim) for the data-parallel driver: `features` is the flat [N, F, T] source (memory-mapped), `rows` the bonafide row
+    indices.  Every rank sums ITS contiguous share of the rows in float64 (rows fetched: 1/world of them), one all-reduce of
+    3 x F doubles makes the statistics identical everywhere -- nobody reads the whole set, nobody un-pickles."""
+    import torch.distributed as dist
+    rows = rows.to(torch.int64).reshape(-1)
+    n = rows.numel()
+    per = -(-n // world) if world > 0 else n
+    mine = rows[rank * per: min(n, (rank + 1) * per)]
+    F = features.shape[1]
+    acc = torch.zeros(3, F, dtype=torch.float64)            # sum, sum of squares, frame count
+    for lo in range(0, mine.numel(), chunk):
+        blk = features[mine[lo:lo + chunk]].double()         # [b, F, T]
+        acc[0] += blk.sum(dim=(0, 2))
+        acc[1] += (blk * blk).sum(dim=(0, 2))
+        acc[2] += blk.shape[0] * blk.shape[2]
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        t = acc.cuda() if dist.get_backend() == "nccl" else acc
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        acc = t.cpu()
+    cnt = acc[2]
+    mean = acc[0] / cnt
+    var = (acc[1] - cnt * mean * mean) / (cnt - 1).clamp(min=1)
+    obj = FeatureNormalizer()
+    obj.mean = mean.float()
+    obj.std = var.clamp(min=0).sqrt().float().clamp(min=1e-8)
+    obj.rows_fetched = int(mine.numel())
+    return obj
+
+
 def _merged(features_path, labels_path):
     return pd.merge(pd.read_pickle(features_path), pd.read_pickle(labels_path), on="uttid", how="inner")
 

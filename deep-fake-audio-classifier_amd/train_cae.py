@@ -17,7 +17,7 @@ from torch.utils.data import DataLoader
 
 from . import distributed as dfa_dist
 from .dataloaders import train_shard_indices
-from .dataset_cae import BonafideDataset, FeatureNormalizer, build_normalizer
+from .dataset_cae import BonafideDataset, FeatureNormalizer, build_normalizer, fit_normalizer_sharded
 from .model_cae import ConvAutoencoder
 from .training import save_checkpoint
 
@@ -75,6 +75,41 @@ def validate_reconstruction_sharded(model, dataset, batch_size, num_workers, dev
     return float(total[0].item() / total[1].item()) if float(total[1].item()) > 0 else None
 
 
+class _NormalizedBatches:
+    """This rank's batches of an epoch from the flat source: IndexedFlatBatcher rows [b, F, T] (pinned staging, async H2D) ->
+    the [b, T, F] view the model takes -> z-score on the device (src/dataset_cae.py:27-30, the dataset's transform)."""
+
+    def __init__(self, batcher, mean, std):
+        self.batcher, self.mean, self.std = batcher, mean, std
+
+    def __len__(self):
+        return len(self.batcher)
+
+    def __iter__(self):
+        for f, _ in self.batcher:
+            yield (f.transpose(1, 2).float() - self.mean) / self.std
+
+
+@torch.no_grad()
+def validate_reconstruction_flat(model, feats, rows, mean, std, batch_size, device, rank, world):
+    """validate_reconstruction over this rank's contiguous share of the bonafide dev rows of the flat source, the z-score fused
+    into the score kernel's loads (model.score(x, mean, std)); ONE all-reduce of (sum, count)."""
+    import torch.distributed as dist
+    from .dataloaders import IndexedFlatBatcher
+    lo, hi = dfa_dist.shard_range(rows.numel(), rank, world)
+    model.eval()
+    total = torch.zeros(2, dtype=torch.float64, device=device)
+    if hi > lo:
+        for f, _ in IndexedFlatBatcher(feats, None, rows[lo:hi], batch_size, device=device):
+            total[0] += model.score(f.transpose(1, 2), mean, std).double().sum()
+            total[1] += f.shape[0]
+    if world > 1:
+        t = total if dist.get_backend() == "nccl" else total.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total = t
+    return float(total[0].item() / total[1].item()) if float(total[1].item()) > 0 else None
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Train the convolutional auto-encoder for anomaly detection (MI355X).")
     p.add_argument("--train-features", default="data/train/features.pkl")
@@ -116,14 +151,33 @@ def main(argv=None):
     ckpt_dir = os.path.join(args.checkpoint_dir, args.run_name)
     os.makedirs(ckpt_dir, exist_ok=True)
     best_path, last_path = os.path.join(ckpt_dir, "cae_best.pt"), os.path.join(ckpt_dir, "cae_last.pt")
-    if args.normalizer_path and os.path.exists(args.normalizer_path):
-        normalizer = FeatureNormalizer.load(args.normalizer_path)
+    flat = world > 1                 # data-parallel input path: each rank reads only what it consumes
+    if flat:
+        # rank 0 alone converts a features.pkl into the flat memory-mapped file; every rank maps it, fits the normaliser on its
+        # share of the bonafide rows (one all-reduce) and fetches exactly the rows of its batches -- no rank un-pickles or holds
+        # the whole set (the classifiers' path: train.py / dataloaders.open_flat)
+        from .dataloaders import IndexedFlatBatcher, open_flat
+        cache = os.path.join(ckpt_dir, "flat_cache")
+        tr_feats, tr_labels, _ = open_flat(args.train_features, args.train_labels, cache, rank, world, "cae_train")
+        dv_feats, dv_labels, _ = open_flat(args.dev_features, args.dev_labels, cache, rank, world, "cae_dev")
+        tr_rows = (tr_labels == 1).nonzero().reshape(-1)
+        dv_rows = (dv_labels == 1).nonzero().reshape(-1)
+        if args.normalizer_path and os.path.exists(args.normalizer_path):
+            normalizer = FeatureNormalizer.load(args.normalizer_path)
+        else:
+            normalizer = fit_normalizer_sharded(tr_feats, tr_rows, rank, world)
+            if rank == 0:
+                normalizer.save(os.path.join(ckpt_dir, "normalizer.pt"))
+        nmean, nstd = normalizer.mean.to(device), normalizer.std.to(device)
+        n_train = int(tr_rows.numel())
     else:
-        normalizer = build_normalizer(args.train_features, args.train_labels)   # deterministic: identical on every rank
-        if rank == 0:
+        if args.normalizer_path and os.path.exists(args.normalizer_path):
+            normalizer = FeatureNormalizer.load(args.normalizer_path)
+        else:
+            normalizer = build_normalizer(args.train_features, args.train_labels)
             normalizer.save(os.path.join(ckpt_dir, "normalizer.pt"))
-    train_ds = BonafideDataset(args.train_features, args.train_labels, normalizer=normalizer, swap_tf=True)
-    val_ds = BonafideDataset(args.dev_features, args.dev_labels, normalizer=normalizer, swap_tf=True)
+        train_ds = BonafideDataset(args.train_features, args.train_labels, normalizer=normalizer, swap_tf=True)
+        val_ds = BonafideDataset(args.dev_features, args.dev_labels, normalizer=normalizer, swap_tf=True)
 
     model = ConvAutoencoder(base_channels=args.base_channels, precision=args.precision).to(device)
     criterion = nn.MSELoss()
@@ -146,15 +200,13 @@ def main(argv=None):
     best, no_improve, last_epoch = None, 0, 0
     for epoch in range(1, args.epochs + 1):
         if world > 1:
-            from torch.utils.data import Subset
-            perm = torch.randperm(len(train_ds), generator=torch.Generator().manual_seed(args.seed + epoch))
-            idx = train_shard_indices(perm, args.batch_size, rank, world)
-            train_loader = DataLoader(Subset(train_ds, idx.tolist()), batch_size=args.batch_size, shuffle=False,
-                                      num_workers=args.num_workers)
-            train_loss = dfa_dist.mean_scalar(train_one_epoch(model, train_loader, criterion, optimizer, device), device)
+            perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(args.seed + epoch))
+            idx = tr_rows[train_shard_indices(perm, args.batch_size, rank, world)]     # rows of the flat source, this rank's share
+            batcher = IndexedFlatBatcher(tr_feats, None, idx, args.batch_size, device=device)
+            train_loss = dfa_dist.mean_scalar(train_one_epoch(model, _NormalizedBatches(batcher, nmean, nstd), criterion, optimizer, device), device)
             dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
             model._prepared = None
-            val_mse = validate_reconstruction_sharded(model, val_ds, args.batch_size, args.num_workers, device, rank, world)
+            val_mse = validate_reconstruction_flat(model, dv_feats, dv_rows, nmean, nstd, args.batch_size, device, rank, world)
         else:
             train_loss = train_one_epoch(model, train_loader, criterion, optimizer, device)
             val_mse = validate_reconstruction(model, val_loader, device)

@@ -250,3 +250,63 @@ def test_world_size_2_flat_input_path(tmp_path):
     world, port = 2, 31500 + (os.getpid() % 2000)
     mp.spawn(_worker_flat_input, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"flat_ok{r}") for r in range(world))
+
+
+def _worker_cae_flat_input(rank, world, port, tmp):
+    """Round 3: the auto-encoder's data-parallel input path (train_cae.py under torchrun; src/train_cae.py:108-160 builds the
+    normaliser and the bonafide datasets on one GPU).  Rank 0 alone converts the pickles; the normaliser is fitted from each
+    rank's share of the bonafide rows + one all-reduce and equals FeatureNormalizer.fit on the whole bonafide set; a rank's
+    batches are its rows of the flat source, z-scored as the reference's dataset does."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import pandas as pd
+    import dfa_amd  # noqa: F401
+    from dfa_amd import distributed as D
+    from dfa_amd.dataloaders import IndexedFlatBatcher, open_flat, train_shard_indices
+    from dfa_amd.dataset_cae import FeatureNormalizer, fit_normalizer_sharded
+    from dfa_amd.train_cae import _NormalizedBatches
+    D.init(backend="gloo")
+    n, F, T, bs = 41, 8, 7, 3
+    fpath, lpath = os.path.join(tmp, "features.pkl"), os.path.join(tmp, "labels.pkl")
+    g = torch.Generator().manual_seed(3)
+    feats_list = [torch.randn(F, T, generator=g) * (1.0 + 0.1 * i) + 0.3 * i for i in range(n)]      # same on every rank (seeded)
+    labels_list = [1 if (i % 3) else 0 for i in range(n)]
+    if rank == 0:
+        pd.DataFrame({"uttid": [f"u{i:03d}" for i in range(n)], "features": feats_list}).to_pickle(fpath)
+        pd.DataFrame({"uttid": [f"u{i:03d}" for i in range(n)], "label": labels_list}).to_pickle(lpath)
+    dist.barrier()
+    real_read = pd.read_pickle
+    if rank != 0:
+        def deny(path, *a, **k):
+            raise AssertionError(f"rank {rank} un-pickled {path}")
+        pd.read_pickle = deny
+    feats, labels, _ = open_flat(fpath, lpath, os.path.join(tmp, "cache"), rank, world, "cae_train")
+    pd.read_pickle = real_read
+    rows = (labels == 1).nonzero().reshape(-1)
+    assert rows.tolist() == [i for i in range(n) if labels_list[i] == 1]
+    norm = fit_normalizer_sharded(feats, rows, rank, world)
+    want = FeatureNormalizer().fit([feats_list[i].transpose(0, 1) for i in rows.tolist()])           # the reference's fit, whole set
+    assert torch.allclose(norm.mean, want.mean, rtol=1e-5, atol=1e-6) and torch.allclose(norm.std, want.std, rtol=1e-5, atol=1e-6)
+    assert norm.rows_fetched <= -(-rows.numel() // world)                                            # its share, not the set
+    both = [torch.zeros(2, F) for _ in range(world)]
+    dist.all_gather(both, torch.stack([norm.mean, norm.std]))
+    assert all(torch.equal(b, both[0]) for b in both)                                                # identical on every rank
+    perm = torch.randperm(rows.numel(), generator=torch.Generator().manual_seed(9))
+    idx = rows[train_shard_indices(perm, bs, rank, world)]
+    batcher = IndexedFlatBatcher(feats, None, idx, bs, device="cpu")
+    k = 0
+    for x in _NormalizedBatches(batcher, norm.mean, norm.std):
+        assert tuple(x.shape) == (bs, T, F)
+        for j in range(bs):
+            ref = (feats_list[int(idx[k])].transpose(0, 1) - norm.mean) / norm.std
+            assert torch.allclose(x[j], ref, rtol=1e-6, atol=1e-6)
+            k += 1
+    assert k == idx.numel() and batcher.rows_fetched == idx.numel()
+    open(os.path.join(tmp, f"cae_flat_ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_world_size_2_cae_flat_input_path(tmp_path):
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_cae_flat_input, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"cae_flat_ok{r}") for r in range(world))
