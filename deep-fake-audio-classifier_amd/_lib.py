@@ -51,6 +51,7 @@ SYMBOLS = [
                                               C.c_int, C.c_float, C.c_uint64, C.c_uint64]),
     ("dfa_cnn1d_set_train_augment", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_float, C.c_uint64, C.c_uint64]),
+    ("dfa_ctx_set_bn_sync", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     ("dfa_adamw_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]),
     ("dfa_cnn1d_set_params", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
@@ -197,6 +198,32 @@ class Context:
         ms, n = C.c_float(), C.c_int()
         check(self.handle, self.lib.dfa_ctx_timing_read(self.handle, slot, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    # ---- synchronised BatchNorm --------------------------------------------------------------------------------
+    BN_SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+    def set_bn_sync(self, process_group=None, enable=True):
+        """Synchronised BatchNorm for data-parallel CNN2D training (dfa_ctx_set_bn_sync): every BatchNorm layer's per-channel
+        sums are added over the ranks of `process_group` between their reduction and their use, so N ranks x B utterances
+        behave like one rank x N*B.  enable=False (or a world of 1) restores local statistics."""
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group) if (enable and dist.is_available() and dist.is_initialized()) else 1
+        if not enable or world == 1:
+            check(self.handle, self.lib.dfa_ctx_set_bn_sync(self.handle, None, None, 1, None, 0))
+            self._bn_sync = None
+            return
+        buf = torch.zeros(1024, dtype=torch.float32, device=self.device)
+
+        def hook(_user, _buf, count):
+            try:       # in place, ordered after the work already on the current (= the context's) stream
+                dist.all_reduce(buf[:count], op=dist.ReduceOp.SUM, group=process_group)
+                return 0
+            except Exception:   # noqa: BLE001 -- reported through the C ABI's error path
+                return -1
+        cb = self.BN_SYNC_FN(hook)
+        self._bn_sync = (buf, cb, hook)                 # keep the tensor and the callback object alive
+        check(self.handle, self.lib.dfa_ctx_set_bn_sync(self.handle, C.cast(cb, C.c_void_p), None, world,
+                                                        C.c_void_p(buf.data_ptr()), buf.numel()))
 
     def clock_read(self):
         """(median, min, max GHz, workgroups) of the last bf16 CNN2D block-3 launch run with set_option("clock_probe", 1)."""

@@ -57,6 +57,20 @@ struct Cnn2dState {
   int train_dgrad_m16 = 0;                // the d2/d3 images are in the 16x16x32 order of conv_split.hip (bf16 mode)
 };
 
+// Synchronised BatchNorm for data-parallel training ("SyncBN via two small all-reduces per layer -- makes
+// N GPUs x B equal to one GPU x N*B up to summation order"): between a layer's statistics reduction and its use the library copies
+// the per-channel sums into `buf` and calls fn(user, buf, count) on the host thread; the callee enqueues an in-place SUM all-reduce
+// of buf[0 .. count) ordered after the work already on the context's stream (torch.distributed does) and returns 0.
+struct BnSync {
+  int (*fn)(void* user, float* buf, int count) = nullptr;
+  void* user = nullptr;
+  int world = 1;
+  float* buf = nullptr;   // caller-owned device buffer, >= 256 floats
+};
+// local sums -> the sums the apply / finalize stage uses (buf after the all-reduce, or `sums` itself when not synchronising) and
+// the factor that turns 1 / n_local into 1 / n_global
+hipError_t bn_sync_sums(const BnSync* sy, const float* sums, int count, hipStream_t s, const float** sums_apply, float* inv_scale);
+
 struct Cnn1dState {
   const float* p[DFA_CNN1D_NPARAMS] = {nullptr};
   bool have_params = false;
@@ -104,6 +118,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
+  dfa::BnSync bn_sync;         // dfa_ctx_set_bn_sync: synchronised BatchNorm statistics in dfa_cnn2d_forward_train / _backward
   int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
   int fuse_conv1 = 1;          // bf16 mode: blocks 1 and 2 in one kernel (conv12_fused.hip; fp32 features are rounded to bf16 on load); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
@@ -289,13 +304,13 @@ hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, cons
                                 const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s, float* msum = nullptr);
 hipError_t launch_bn_bwd_meant_saved(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
                                      const float* beta, const float* demb, const float* msum, float* partial, float* sums,
-                                     void* dz, int B, int H, int W, int C, hipStream_t s);
+                                     void* dz, int B, int H, int W, int C, hipStream_t s, const BnSync* sync = nullptr);
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
                              int B, int K, hipStream_t s, int tc = 0, int tw = 0);
 int bn_bwd_blocks(int B, int H, int W, int* pix_per_block);
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
-                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch = nullptr);
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch = nullptr, const BnSync* sync = nullptr);
 hipError_t launch_bce_smooth(const float* logits, const float* labels, float eps, int B, float* loss, float* dlogits,
                              hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
@@ -309,7 +324,7 @@ hipError_t launch_conv1_mfma(int mode, const void* x, int64_t sb, int64_t st, in
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
-                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1, const AugCfg* aug = nullptr);
+                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw = 1, const AugCfg* aug = nullptr, float inv_n_scale = 1.0f);
 hipError_t launch_conv1_bwd_finalize(const float* rec, const float* xxs, const float* w, const float* bconv, const float* mean,
                                      const float* invstd, const float* gamma, double n, float* dw, float* db, float* dgamma,
                                      float* dbeta, hipStream_t s, int derive_s2 = 0);

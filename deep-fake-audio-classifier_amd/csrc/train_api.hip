@@ -77,6 +77,22 @@ TrainPlan plan_train(int B, int T, int F, int prec) {
 }
 
 struct StatPtrs { float *mean, *var, *invstd; };
+// BatchNorm batch statistics from the per-workgroup records partial[nparts][C][2].  Synchronised BatchNorm (dfa_ctx_set_bn_sync):
+// the records are first reduced to one [C][2] record in the caller's buffer, summed over the ranks by the caller's hook, and the
+// statistics come from those sums and the global count -- every rank ends with the same mean / variance / running statistics.
+static int finalize_bn_stats(dfa_ctx* ctx, const float* partial, int nparts, int C, double n, float* mean, float* var, float* invstd,
+                             float* rm, float* rv, float momentum, float* scratch) {
+  const dfa::BnSync& sy = ctx->bn_sync;
+  hipStream_t s = ctx->stream;
+  if (!sy.fn) {
+    DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nparts, C, n, mean, var, invstd, rm, rv, momentum, s));
+    return DFA_OK;
+  }
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nparts, C * 2, 1.0f, sy.buf, s, scratch));
+  if (sy.fn(sy.user, sy.buf, C * 2) != 0) return fail(ctx, DFA_E_HIP, "the BatchNorm synchronisation hook failed (forward statistics, %d channels)", C);
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(sy.buf, 1, C, n * (double)sy.world, mean, var, invstd, rm, rv, momentum, s));
+  return DFA_OK;
+}
 StatPtrs stat_ptrs(char* ws, const TrainPlan& pl, int layer) {
   const int off[3] = {0, 32, 96}, C[3] = {32, 64, 128};
   float* base = (float*)(ws + pl.stats);
@@ -177,7 +193,9 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   // augmentation armed by dfa_cnn2d_set_train_augment: one-shot, folded into the three kernels that read x
   m.train_aug = armed;
   const AugCfg* aug = m.train_aug.on ? &m.train_aug : nullptr;
-  m.train_c1_fused = ctx->conv1_bwd_fused ? 1 : 0;
+  // synchronised BatchNorm needs the layer's (sum dy, sum dy*xhat) BEFORE the weight gradient is formed: block 1 then takes the
+  // two-pass vector path (reduce -> hook -> weight gradient), not the one-pass moment algebra
+  m.train_c1_fused = (ctx->conv1_bwd_fused && !ctx->bn_sync.fn) ? 1 : 0;
   // matrix-core passes: bf16 mode on bf16 features without a folded augmentation (its noise makes x non-bf16), fused backward
   // (the backward reads da1 with the dropout keep mask already applied by the 16x16x32 data-gradient kernel)
   m.train_c1_mfma = (ctx->conv1_mfma && m.train_c1_fused && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && !aug && F <= 224 &&
@@ -188,7 +206,8 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   else
   DFA_HIP_CHECK(ctx, launch_conv1_train(m.train_c1_fused ? C1M_STATS_XX : C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1],
                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prec, partial, B, T, F, dc, s, 1, aug));
-  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nb1f, 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, s));
+  { const int rc = finalize_bn_stats(ctx, partial, nb1f, 32, (double)B * T * F, s1.mean, s1.var, s1.invstd, rm[0], rv[0], momentum, partial + (size_t)nb1f * 352);
+    if (rc != DFA_OK) return rc; }
   if (m.train_c1_fused) {   // XX[9][9] | Xs[9] (block records of 96 floats behind the [32][2] records) -> the sums region, for backward
     float* xxs = (float*)(ws + pl.sums) + 2 * (32 + 64 + 128) + 352;
     DFA_HIP_CHECK(ctx, launch_reduce_partials(partial + (size_t)nb1f * 64, nb1f, 96, 1.0f, xxs, s, partial + (size_t)nb1f * 160));
@@ -208,7 +227,8 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     DFA_HIP_CHECK(ctx, launch_train_fwd2(prec, a, s));
   }
   StatPtrs s2 = stat_ptrs(ws, pl, 1);
-  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * nstrips, 64, (double)B * pl.H1 * F, s2.mean, s2.var, s2.invstd, rm[1], rv[1], momentum, s));
+  { const int rc = finalize_bn_stats(ctx, partial, B * nstrips, 64, (double)B * pl.H1 * F, s2.mean, s2.var, s2.invstd, rm[1], rv[1], momentum, partial + (size_t)B * nstrips * 128);
+    if (rc != DFA_OK) return rc; }
   dc.layer = 2;
   DFA_HIP_CHECK(ctx, launch_bn_relu_pool_drop(prec, ws + pl.z2, s2.mean, s2.invstd, p[8], p[9], ws + pl.a2, B, pl.H1, F, 64, dc, s));
   // ---- block 3
@@ -224,7 +244,9 @@ int dfa_cnn2d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     }
   }
   StatPtrs s3 = stat_ptrs(ws, pl, 2);
-  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, B * (fwd3_m16 ? (F + 29) / 30 : nstrips), 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, s));   // conv3_m16 owns 30 columns per strip
+  { const int np3 = B * (fwd3_m16 ? (F + 29) / 30 : nstrips);   // conv3_m16 owns 30 columns per strip
+    const int rc = finalize_bn_stats(ctx, partial, np3, 128, (double)B * pl.H2 * F, s3.mean, s3.var, s3.invstd, rm[2], rv[2], momentum, partial + (size_t)np3 * 256);
+    if (rc != DFA_OK) return rc; }
   float* emb = (float*)(ws + pl.emb);
   DFA_HIP_CHECK(ctx, launch_bn_relu_meant(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], emb, B, pl.H2, F, 128, s, (float*)(ws + pl.msum)));
   if (embedding) DFA_HIP_CHECK(ctx, hipMemcpyAsync(embedding, emb, (size_t)B * 128 * F * 4, hipMemcpyDeviceToDevice, s));
@@ -256,11 +278,12 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
   float *sm1 = sums_ptr(ws, pl, 0), *sm2 = sums_ptr(ws, pl, 1), *sm3 = sums_ptr(ws, pl, 2);
   float* c1rec = (float*)(ws + pl.sums) + 2 * (32 + 64 + 128);
   float* demb = (float*)(ws + pl.demb);
+  const dfa::BnSync* sync = ctx->bn_sync.fn ? &ctx->bn_sync : nullptr;     // synchronised BatchNorm (dfa_ctx_set_bn_sync)
   // classifier
   DFA_HIP_CHECK(ctx, launch_linear_bwd(dlogits, p[18], (const float*)(ws + pl.emb), demb, grads[12], grads[13], B, 128 * F, s, 128, F));
   // block 3: BN backward (upstream = mean_T then Linear), weight gradient, data gradient
   DFA_HIP_CHECK(ctx, launch_bn_bwd_meant_saved(prec, ws + pl.z3, s3.mean, s3.invstd, p[14], p[15], demb, (const float*)(ws + pl.msum), partial,
-                                               sm3, ws + pl.dz3, B, pl.H2, F, 128, s));
+                                               sm3, ws + pl.dz3, B, pl.H2, F, 128, s, sync));
   hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm3, grads[10], grads[11], 128);
   DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, 64, 128, ws + pl.dz3, ws + pl.a2, partial, grads[8], grads[9], B, pl.H2, F, kWgradWGs, s));
   {
@@ -276,7 +299,7 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
     int ppb_;
     float* scratch2 = partial + (size_t)bn_bwd_blocks(B, pl.H1, F, &ppb_) * 64 * 2;
     DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL, ws + pl.z2, s2.mean, s2.invstd, p[8], p[9], nullptr, ws + pl.da2, partial, sm2, ws + pl.dz2,
-                                     B, pl.H1, F, 64, dc, s, scratch2));
+                                     B, pl.H1, F, 64, dc, s, scratch2, sync));
   }
   hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm2, grads[6], grads[7], 64);
   DFA_HIP_CHECK(ctx, launch_wgrad3x3(prec, 32, 64, ws + pl.dz2, ws + pl.a1, partial, grads[4], grads[5], B, pl.H1, F, kWgradWGs, s));
@@ -316,9 +339,12 @@ int dfa_cnn2d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
                                         nullptr, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug));
   float* scratch = partial + (size_t)nb1 * 320;
   DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm1, s, scratch));
-  hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm1, grads[2], grads[3], 32);
+  hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm1, grads[2], grads[3], 32);      // dgamma, dbeta: this rank's own sums
+  const float* sm1_a;
+  float isc1;
+  DFA_HIP_CHECK(ctx, bn_sync_sums(sync, sm1, 64, s, &sm1_a, &isc1));                                   // dz1 is formed from the global ones
   DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_WGRAD, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], s1.mean, s1.invstd, p[2], p[3],
-                                        sm1, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug));
+                                        sm1_a, ws + pl.da1, prec, partial, B, T, F, dc, s, 1, aug, isc1));
   DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, c1rec, s, scratch));
   hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, c1rec, grads[0], grads[1]);
   DFA_HIP_CHECK(ctx, hipGetLastError());
@@ -374,6 +400,16 @@ int dfa_cnn1d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shif
   if (!ctx) return DFA_E_NULL_PTR;
   return arm_train_augment(ctx, ctx->cnn1d.aug_armed, enable, T, F, shift, keep_f, tmask_start, tmask_len, fmask_start, fmask_len,
                            jitter_std, seed, offset);
+}
+
+int dfa_ctx_set_bn_sync(dfa_ctx* ctx, dfa_bn_sync_fn fn, void* user, int world, float* buf, int capacity) {
+  if (!ctx) return DFA_E_NULL_PTR;
+  ctx->bn_sync = dfa::BnSync{};
+  if (!fn) return DFA_OK;
+  if (world < 1) return fail(ctx, DFA_E_BAD_SHAPE, "world must be >= 1 (got %d)", world);
+  if (!buf || capacity < 256) return fail(ctx, DFA_E_NULL_PTR, "the synchronisation buffer must hold at least 256 floats");
+  ctx->bn_sync.fn = fn; ctx->bn_sync.user = user; ctx->bn_sync.world = world; ctx->bn_sync.buf = buf;
+  return DFA_OK;
 }
 
 int dfa_bce_smooth_fwd_bwd(dfa_ctx* ctx, const float* logits, const float* labels, float label_smoothing, int B,

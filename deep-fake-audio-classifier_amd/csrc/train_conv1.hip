@@ -281,11 +281,11 @@ int conv1_train_blocks(int B, int T, int F) { (void)T; return B * C1T_GY * ((F +
 hipError_t launch_conv1_train(int mode, const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* w,
                               const float* bconv, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, const float* sums, const void* da1, int prec, float* partial, int B,
-                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw, const AugCfg* augp) {
+                              int T, int F, const DropCfg& dc, hipStream_t s, int poolw, const AugCfg* augp, float inv_n_scale) {
   AugCfg aug{};
   if (augp) aug = *augp;
   dim3 grid((F + C1T_C - 1) / C1T_C, C1T_GY, B), block(256);
-  const float inv_n = (float)(1.0 / ((double)B * T * F));
+  const float inv_n = (float)(1.0 / ((double)B * T * F)) * inv_n_scale;     // (synchronised BatchNorm: 1 / world -> 1 / n_global)
 #define DFA_C1T(TXX, TT, MODE)                                                                                        \
   do {                                                                                                                 \
     if (poolw == 2)                                                                                                    \

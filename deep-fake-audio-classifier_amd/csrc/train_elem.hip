@@ -816,7 +816,7 @@ hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, cons
 // reduce (3 floats per position) -> fixed-order second stage -> the usual apply pass (z -> dz).
 hipError_t launch_bn_bwd_meant_saved(int prec, const void* z, const float* mean, const float* invstd, const float* gamma,
                                      const float* beta, const float* demb, const float* msum, float* partial, float* sums,
-                                     void* dz, int B, int H, int W, int C, hipStream_t s) {
+                                     void* dz, int B, int H, int W, int C, hipStream_t s, const BnSync* sync) {
   const size_t npos = (size_t)B * W;
   const int PL = 256 / (C / 8);
   const int ppb = 8 * PL;
@@ -827,13 +827,17 @@ hipError_t launch_bn_bwd_meant_saved(int prec, const void* z, const float* mean,
   if (e != hipSuccess) return e;
   e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s, nullptr);
   if (e != hipSuccess) return e;
+  const float* sums_a;
+  float isc;
+  e = bn_sync_sums(sync, sums, C * 2, s, &sums_a, &isc);          // synchronised BatchNorm: global sums, global count
+  if (e != hipSuccess) return e;
   dim3 g2((unsigned)(((size_t)B * W * (C / 8) + 255) / 256));
-  const float inv_n = (float)(1.0 / ((double)B * H * W));
+  const float inv_n = (float)(1.0 / ((double)B * H * W)) * isc;
   if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_meant_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, sums,
+    hipLaunchKernelGGL(bn_bwd_apply_meant_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, sums_a,
                        demb, (bf16_t*)dz, B, H, W, C, inv_n);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_meant_kernel<float>, g2, dim3(256), 0, s, (const float*)z, mean, invstd, gamma, beta, sums,
+    hipLaunchKernelGGL(bn_bwd_apply_meant_kernel<float>, g2, dim3(256), 0, s, (const float*)z, mean, invstd, gamma, beta, sums_a,
                        demb, (float*)dz, B, H, W, C, inv_n);
   return hipGetLastError();
 }
@@ -842,6 +846,18 @@ hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* 
                              int B, int K, hipStream_t s, int tc, int tw) {
   hipLaunchKernelGGL(linear_bwd_kernel, dim3((K + 31) / 32), dim3(256), 0, s, dlogits, w, emb, demb, dw, db, B, K, tc, tw);
   return hipGetLastError();
+}
+
+hipError_t bn_sync_sums(const BnSync* sy, const float* sums, int count, hipStream_t s, const float** sums_apply, float* inv_scale) {
+  *sums_apply = sums;
+  *inv_scale = 1.0f;
+  if (!sy || !sy->fn) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(sy->buf, sums, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return e;
+  if (sy->fn(sy->user, sy->buf, count) != 0) return hipErrorUnknown;     // the caller's collective failed
+  *sums_apply = sy->buf;
+  *inv_scale = 1.0f / (float)sy->world;
+  return hipSuccess;
 }
 
 int bn_bwd_blocks(int B, int H, int W, int* pix_per_block) {
@@ -855,7 +871,7 @@ int bn_bwd_blocks(int B, int H, int W, int* pix_per_block) {
 // two-level reduction of the block records (nullptr: one level)
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
-                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch) {
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch, const BnSync* sync) {
   int ppb;
   int nblk = bn_bwd_blocks(B, H, W, &ppb);
   if ((size_t)B * H * W >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit pixel indices in the generic kernels
@@ -868,6 +884,8 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
   const int ppb2 = 16 * PL;                       // pixels per block of the apply pass: 16 chunks per thread
   dim3 g2((unsigned)(((size_t)B * H * W + ppb2 - 1) / ppb2));
   const float inv_n = (float)(1.0 / ((double)B * H * W));
+  const float* sums_a = sums;      // what the apply stage reads: the all-reduced copy under synchronised BatchNorm
+  float isc = 1.0f;
 #define DFA_BN_BWD_POOL(TT)                                                                                            \
   do {                                                                                                                 \
     const int ppp = ppb / 2;                                                                                           \
@@ -878,11 +896,13 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
     if (e != hipSuccess) return e;                                                                                     \
     e = launch_reduce_partials(partial, nb, C * 2, 1.0f, sums, s, scratch);                                            \
     if (e != hipSuccess) return e;                                                                                     \
+    e = bn_sync_sums(sync, sums, C * 2, s, &sums_a, &isc);                                                             \
+    if (e != hipSuccess) return e;                                                                                     \
     if (dz) {   /* 0.435 vs 0.475 ms for the generic kernel at [256,160,180,64] */                                      \
       const int ppp2 = 8 * PL;                                                                                         \
       dim3 g3((unsigned)(((size_t)B * (H / 2) * W + ppp2 - 1) / ppp2));                                                \
-      hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<TT>, g3, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \
-                         (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n, ppp2);                                         \
+      hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<TT>, g3, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums_a, \
+                         (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n * isc, ppp2);                                   \
     }                                                                                                                  \
   } while (0)
 #define DFA_BN_BWD(TT, SRC)                                                                                            \
@@ -893,9 +913,11 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
     if (e != hipSuccess) return e;                                                                                     \
     e = launch_reduce_partials(partial, nblk, C * 2, 1.0f, sums, s, scratch);                                                     \
     if (e != hipSuccess) return e;                                                                                     \
+    e = bn_sync_sums(sync, sums, C * 2, s, &sums_a, &isc);                                                             \
+    if (e != hipSuccess) return e;                                                                                     \
     if (dz)                                                                                                            \
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums, \
-                         demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n, ppb2);                                        \
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums_a, \
+                         demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n * isc, ppb2);                                  \
   } while (0)
   if (prec == DFA_PREC_BF16) {
     if (src == SRC_MEANT) DFA_BN_BWD(bf16_t, SRC_MEANT);

@@ -407,11 +407,17 @@ class NativeTrainer(_FlatAdamW):
     CNN2D and CNN1D (chosen by the model's class)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, label_smoothing=0.0,
-                 process_group=None):
+                 process_group=None, sync_bn=False):
         if not (0.0 <= label_smoothing < 0.5):
             raise ValueError("--label-smoothing must be in [0, 0.5)")          # src/train.py:308-309
         super().__init__(model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, process_group=process_group)
         self.label_smoothing = label_smoothing
+        # sync_bn (CNN2D, world > 1): BatchNorm statistics over the GLOBAL batch (six 2C-float all-reduces per step through the
+        # C ABI's hook): N ranks x B then train like one rank x N*B; the default is DistributedDataParallel's local statistics
+        self.sync_bn = bool(sync_bn)
+        if self.sync_bn and type(model).__name__ != "CNN2D":
+            raise ValueError("sync_bn is implemented for the CNN2D")
+        _lib.Context.get(self.flat_p.device).set_bn_sync(process_group, enable=self.sync_bn)
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
         self.dlogits = None
         self.kind = "cnn1d" if type(model).__name__ == "CNN1D" else "cnn2d"
