@@ -438,6 +438,65 @@ hipError_t launch_pack_conv1d_terms(const float* wf, void* wx, int cin, int cout
   return hipGetLastError();
 }
 
+// The five images of a training step (forward layers 1-3, data gradients 3 -> 2 and 2 -> 1) in ONE launch, the data-gradient ones read
+// straight from the layer's own weight: W'[c][o][k'] = W[o][c][2 - k'] (a Conv1d with Cin' = Cout, Cout' = Cin) -- seven launches
+// (five packs + two transposes) of ~4.5 us each otherwise, in a step of 0.6 ms.
+struct Conv1dPackAll {
+  const float* w[5];     // the layer's weight [Cout][Cin][3] (for a flipped entry: the FORWARD layer's weight)
+  uint4* dst[5];
+  int cin[5], cout[5], nks[5], flip[5], begin[6];   // cin / cout of the convolution the image serves; fragment range [begin[i], begin[i+1])
+  int terms;
+  float* zero_bias;      // [256] zeroed here (the data gradients' bias)
+};
+__global__ void pack_conv1d_train_all_kernel(Conv1dPackAll a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 256) a.zero_bias[i] = 0.f;
+  if (i >= a.begin[5]) return;
+  int e = 0;
+#pragma unroll
+  for (int q = 1; q < 5; ++q) e += (i >= a.begin[q]) ? 1 : 0;
+  const int li = i - a.begin[e], cin = a.cin[e], cout = a.cout[e], nks = a.nks[e];
+  const int lane = li & 63;
+  int rest = li >> 6;
+  const int ks = rest % nks; rest /= nks;
+  const int tap = rest % 3, m = rest / 3;
+  const int co = 32 * m + (lane & 31), hh = lane >> 5;
+  const float* w = a.w[e];
+  bf16_t t0[8], t1[8], t2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = 16 * ks + 8 * hh + j;
+    float v = 0.f;
+    if (ci < cin) v = a.flip[e] ? w[((size_t)ci * cout + co) * 3 + (2 - tap)]      // forward weight [o = ci'][c = co'][2 - k'], its Cin = cout'
+                                : w[((size_t)co * cin + ci) * 3 + tap];
+    t0[j] = float_to_bf16(v);
+    const float r1 = v - bf16_to_float(t0[j]);
+    t1[j] = float_to_bf16(r1);
+    t2[j] = float_to_bf16(r1 - bf16_to_float(t1[j]));
+  }
+  uint4* dst = a.dst[e] + ((size_t)((m * 3 + tap) * nks + ks) * a.terms) * 64 + lane;
+  dst[0] = *reinterpret_cast<const uint4*>(t0);
+  dst[64] = *reinterpret_cast<const uint4*>(t1);
+  if (a.terms == 3) dst[128] = *reinterpret_cast<const uint4*>(t2);
+}
+// w1, w2, w3: the three Conv1d weights [32][F][3], [64][32][3], [128][64][3]; dst[0..4]: forward 1-3, data gradients 3 -> 2, 2 -> 1
+hipError_t launch_pack_conv1d_train_all(const float* w1, const float* w2, const float* w3, void* const* dst, int F, int terms, float* zero_bias,
+                                        hipStream_t s) {
+  Conv1dPackAll a{};
+  const float* w[5] = {w1, w2, w3, w3, w2};
+  const int cin[5] = {F, 32, 64, 128, 64}, cout[5] = {32, 64, 128, 64, 32}, flip[5] = {0, 0, 0, 1, 1};
+  a.begin[0] = 0;
+  for (int i = 0; i < 5; ++i) {
+    a.w[i] = w[i]; a.dst[i] = (uint4*)dst[i]; a.cin[i] = cin[i]; a.cout[i] = cout[i]; a.flip[i] = flip[i];
+    a.nks[i] = cnn1d_x3_nks(cin[i]);
+    a.begin[i + 1] = a.begin[i] + (cout[i] / 32) * 3 * a.nks[i] * 64;
+  }
+  a.terms = terms; a.zero_bias = zero_bias;
+  const int total = a.begin[5] > 256 ? a.begin[5] : 256;
+  hipLaunchKernelGGL(pack_conv1d_train_all_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // 8 floats -> TERMS bf16 fragments (element j in bf16 position j): v = f[0] + f[1] (+ f[2]), exactly for TERMS = 3
 template <int TERMS>
 __device__ __forceinline__ void split8n(const float (&v)[8], uint4 (&f)[TERMS]) {

@@ -271,6 +271,8 @@ hipError_t launch_conv1d_x3(const float* x, int64_t sb, const void* wx, const fl
                             int terms, hipStream_t s, int mode = 1, const AugCfg* aug = nullptr);
 size_t conv1d_terms_pack_bytes(int cin, int cout, int terms);
 hipError_t launch_pack_conv1d_terms(const float* wf, void* wx, int cin, int cout, int terms, hipStream_t s);
+hipError_t launch_pack_conv1d_train_all(const float* w1, const float* w2, const float* w3, void* const* dst, int F, int terms, float* zero_bias,
+                                        hipStream_t s);
 hipError_t launch_conv1d_wgrad(const float* dz, const float* h, int64_t hsb, int64_t hsc, int64_t hst, float* partial,
                                float* dw, float* db, int B, int Cin, int Cout, int T, hipStream_t s, const AugCfg* aug = nullptr, int x3 = 0);
 hipError_t launch_conv1d_dgrad_pack(const float* w, float* wt, float* zero_bias, int cin, int cout, hipStream_t s);

@@ -531,13 +531,15 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
   }
   const float* const* p = m.p;
   hipStream_t s = ctx->stream;
-  DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[6], m.wt[0], m.zero_bias, 32, 64, s));
-  DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[12], m.wt[1], m.zero_bias, 64, 128, s));
   const int x3 = ctx->cnn1d_train_x3, terms = (x3 == 3) ? 2 : 3;
-  if (x3) {
-    const float* wsrc[5] = {p[0], p[6], p[12], m.wt[1], m.wt[0]};
-    for (int i = 0; i < 5; ++i) DFA_HIP_CHECK(ctx, launch_pack_conv1d_terms(wsrc[i], m.wx3[i], xcin[i], xcout[i], terms, s));
+  // the fp32 data-gradient images are only read by the vector-ALU fallback (T > 384, option 0)
+  const bool dgrad_x3 = x3 && conv1d_x3_supports((const float*)workspace, (int64_t)128 * T, T, 1, (const float*)workspace, T, 128, 64, terms) &&
+                        conv1d_x3_supports((const float*)workspace, (int64_t)64 * T, T, 1, (const float*)workspace, T, 64, 32, terms);
+  if (!dgrad_x3) {
+    DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[6], m.wt[0], m.zero_bias, 32, 64, s));
+    DFA_HIP_CHECK(ctx, launch_conv1d_dgrad_pack(p[12], m.wt[1], m.zero_bias, 64, 128, s));
   }
+  if (x3) DFA_HIP_CHECK(ctx, launch_pack_conv1d_train_all(p[0], p[6], p[12], m.wx3, F, terms, m.zero_bias, s));   // all five images, one launch
   m.train_x3 = x3;
   DropCfg dc{};
   dc.thresh = (p_drop > 0.f) ? (unsigned)((double)p_drop * 4294967296.0) : 0u;
