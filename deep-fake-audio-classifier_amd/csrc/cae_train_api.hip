@@ -91,13 +91,26 @@ St stat_of(char* ws, const CaeTrainPlan& pl, int layer, int C) {
 }
 float* sums_of(char* ws, const CaeTrainPlan& pl, int layer) { return (float*)(ws + pl.sums) + 2 * kBnOff[layer]; }
 
+// batch statistics from the block records partial[nparts][C][2]; under synchronised BatchNorm (dfa_ctx_set_bn_sync) the records are
+// reduced to one [C][2] record in the caller's buffer, summed over the ranks by the hook, and the global count is used
+int finalize_records(dfa_ctx* ctx, const float* partial, int nparts, int C, double n, const St& st, float* rm, float* rv, float momentum) {
+  const dfa::BnSync& sy = ctx->bn_sync;
+  if (!sy.fn) {
+    DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nparts, C, n, st.mean, st.var, st.invstd, rm, rv, momentum, ctx->stream));
+    return DFA_OK;
+  }
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nparts, C * 2, 1.0f, sy.buf, ctx->stream, nullptr));
+  if (sy.fn(sy.user, sy.buf, C * 2) != 0) return fail(ctx, DFA_E_HIP, "the BatchNorm synchronisation hook failed (forward statistics, %d channels)", C);
+  DFA_HIP_CHECK(ctx, launch_bn_finalize(sy.buf, 1, C, n * (double)sy.world, st.mean, st.var, st.invstd, rm, rv, momentum, ctx->stream));
+  return DFA_OK;
+}
+
 int finalize_stats(dfa_ctx* ctx, int prec, const void* z, size_t npix, int C, const St& st, float* partial, float* rm,
                    float* rv, float momentum) {
   int ppb;
   const int nblk = cl_stats_blocks(npix, &ppb);
   DFA_HIP_CHECK(ctx, launch_cl_stats(prec, z, partial, npix, C, ctx->stream));
-  DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nblk, C, (double)npix, st.mean, st.var, st.invstd, rm, rv, momentum, ctx->stream));
-  return DFA_OK;
+  return finalize_records(ctx, partial, nblk, C, (double)npix, st, rm, rv, momentum);
 }
 
 }  // namespace
@@ -174,7 +187,8 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
     St st = stat_of(ws, pl, 0, 32);
     // bf16 mode on bf16 features (F even): the statistics pass (with the 9 x 9 tap moments the fused backward algebra needs) and
     // the backward pass on the matrix cores (train_conv1_mfma.hip, as the CNN2D's block 1), the forward on cae_enc1_mfma.hip
-    m.train_c1_mfma = (ctx->conv1_mfma && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && F <= 224 && !(F & 1) && T >= 4) ? 1 : 0;
+    // (synchronised BatchNorm: the backward needs the layer's sums before the weight gradient is formed -> the two-pass vector path)
+    m.train_c1_mfma = (ctx->conv1_mfma && !ctx->bn_sync.fn && prec == DFA_PREC_BF16 && x_dtype == DFA_DTYPE_BF16 && F <= 224 && !(F & 1) && T >= 4) ? 1 : 0;
     if (m.train_c1_mfma) {
       const int nbm = conv1_mfma_blocks(B, T, F);
       DFA_HIP_CHECK(ctx, launch_conv1_mfma(C1X_STATS, x, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, partial, B, T, F, nodrop, s));
@@ -184,7 +198,8 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
     } else {
       DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_STATS, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], nullptr, nullptr, nullptr, nullptr,
                                             nullptr, nullptr, prec, partial, B, T, F, nodrop, s));
-      DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, st.mean, st.var, st.invstd, rmv(4), rmv(5), momentum, s));
+      { const int rc = finalize_records(ctx, partial, conv1_train_blocks(B, T, F), 32, (double)B * T * F, st, rmv(4), rmv(5), momentum);
+        if (rc != DFA_OK) return rc; }
     }
     DFA_HIP_CHECK(ctx, launch_fold_conv1(p[0], p[1], p[2], p[3], st.mean, st.var, m.tw1, m.tb1, 32, s));
     if (m.train_c1_mfma && ctx->cae_enc1_mfma) {
@@ -253,6 +268,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
   // second-level scratch of the block-record reductions (64 x C x 2 floats): the upper half of the partial buffer -- the records
   // of the BatchNorm / statistics passes (<= 3600 x 512 floats) use a fraction of the lower half (sized for the weight gradients)
   float* scratch2 = partial + pl.partial_bytes / 8;
+  const dfa::BnSync* sync = ctx->bn_sync.fn ? &ctx->bn_sync : nullptr;     // synchronised BatchNorm (dfa_ctx_set_bn_sync)
   const int bf = (prec == DFA_PREC_BF16) ? 1 : 0;
   DropCfg nodrop{};
   // ---- decoder block 4
@@ -272,7 +288,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     St st = stat_of(ws, pl, 4 + l, Cout);
     float* sm = sums_of(ws, pl, 4 + l);
     DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_DIRECT, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], nullptr, ws + pl.dd[l], partial, sm,
-                                     ws + pl.dzd[l], B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s, scratch2));
+                                     ws + pl.dzd[l], B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s, scratch2, sync));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[16 + 4 * l + 2], grads[16 + 4 * l + 3], Cout);
     {  // ConvTranspose2d bias gradient = channel sums of dz over ALL output pixels (the output_padding column included)
       int ppb;
@@ -311,7 +327,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     St st = stat_of(ws, pl, l, kEC[l]);
     float* sm = sums_of(ws, pl, l);
     DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_POOL22, ws + pl.z[l], st.mean, st.invstd, p[6 * l + 2], p[6 * l + 3], nullptr, ws + pl.de[l], partial, sm,
-                                     ws + pl.dz[l], B, pl.H[l], pl.W[l], kEC[l], nodrop, s, scratch2));
+                                     ws + pl.dz[l], B, pl.H[l], pl.W[l], kEC[l], nodrop, s, scratch2, sync));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], kEC[l]);
     if (l == 3) {
       for (int co = 0; co < 2; ++co)
@@ -349,9 +365,12 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_BWD_REDUCE, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], st.mean, st.invstd, p[2], p[3],
                                           nullptr, ws + pl.de[0], prec, partial, B, T, F, nodrop, s, 2));
     DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 64, 1.0f, sm, s, scratch));
-    hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[2], grads[3], 32);
+    hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[2], grads[3], 32);      // dgamma, dbeta: this rank's own sums
+    const float* sm_a;
+    float isc;
+    DFA_HIP_CHECK(ctx, bn_sync_sums(sync, sm, 64, s, &sm_a, &isc));                                    // dz1 is formed from the global ones
     DFA_HIP_CHECK(ctx, launch_conv1_train(C1M_WGRAD, x, x_dtype, stride_b, stride_t, stride_f, p[0], p[1], st.mean, st.invstd, p[2], p[3],
-                                          sm, ws + pl.de[0], prec, partial, B, T, F, nodrop, s, 2));
+                                          sm_a, ws + pl.de[0], prec, partial, B, T, F, nodrop, s, 2, nullptr, isc));
     DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nb1, 320, 1.0f, rec, s, scratch));
     hipLaunchKernelGGL(split_c1_kernel, dim3(1), dim3(320), 0, s, rec, grads[0], grads[1]);
   }

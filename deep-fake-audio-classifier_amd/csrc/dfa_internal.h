@@ -65,7 +65,7 @@ struct BnSync {
   int (*fn)(void* user, float* buf, int count) = nullptr;
   void* user = nullptr;
   int world = 1;
-  float* buf = nullptr;   // caller-owned device buffer, >= 256 floats
+  float* buf = nullptr;   // caller-owned device buffer, >= 512 floats (2 x the widest layer's channels)
 };
 // local sums -> the sums the apply / finalize stage uses (buf after the all-reduce, or `sums` itself when not synchronising) and
 // the factor that turns 1 / n_local into 1 / n_global
@@ -118,7 +118,7 @@ struct dfa_ctx {
   hipStream_t stream = nullptr;
   char err[512] = {0};
   void* zero_page = nullptr;   // 256 zero bytes: source of out-of-image chunks for LDS-DMA staging
-  dfa::BnSync bn_sync;         // dfa_ctx_set_bn_sync: synchronised BatchNorm statistics in dfa_cnn2d_forward_train / _backward
+  dfa::BnSync bn_sync;         // dfa_ctx_set_bn_sync: synchronised BatchNorm statistics in the three models' forward_train / backward
   int block3_m16 = 1;          // bf16 block 3 on v_mfma_f32_16x16x32_bf16 (conv3_m16.hip); 0 = the 32x32x16 kernel
   int fuse_conv1 = 1;          // bf16 mode: blocks 1 and 2 in one kernel (conv12_fused.hip; fp32 features are rounded to bf16 on load); 0 = two kernels
   int lds_pipe = 1;            // 1 = asm-pipelined LDS fragment reads where instantiated, 0 = compiler-scheduled twins (test hook)
@@ -265,7 +265,7 @@ hipError_t launch_cm_bn_relu_meant(const float* z, const float* mean, const floa
                                    const float* beta, float* pooled, int B, int C, int T, hipStream_t s);
 hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* up, float* partial, float* sums, float* dz, int B, int C,
-                            int T, const DropCfg& dc, hipStream_t s);
+                            int T, const DropCfg& dc, hipStream_t s, const BnSync* sync = nullptr);
 bool conv1d_x3_supports(const float* x, int64_t sb, int64_t sc, int64_t st, const float* z, int T, int Cin, int Cout, int terms);
 hipError_t launch_conv1d_x3(const float* x, int64_t sb, const void* wx, const float* bias, float* z, int B, int Cin, int Cout, int T,
                             int terms, hipStream_t s, int mode = 1, const AugCfg* aug = nullptr);

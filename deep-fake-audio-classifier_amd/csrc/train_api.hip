@@ -407,7 +407,7 @@ int dfa_ctx_set_bn_sync(dfa_ctx* ctx, dfa_bn_sync_fn fn, void* user, int world, 
   ctx->bn_sync = dfa::BnSync{};
   if (!fn) return DFA_OK;
   if (world < 1) return fail(ctx, DFA_E_BAD_SHAPE, "world must be >= 1 (got %d)", world);
-  if (!buf || capacity < 256) return fail(ctx, DFA_E_NULL_PTR, "the synchronisation buffer must hold at least 256 floats");
+  if (!buf || capacity < 512) return fail(ctx, DFA_E_NULL_PTR, "the synchronisation buffer must hold at least 512 floats");
   ctx->bn_sync.fn = fn; ctx->bn_sync.user = user; ctx->bn_sync.world = world; ctx->bn_sync.buf = buf;
   return DFA_OK;
 }
@@ -567,9 +567,9 @@ int dfa_cnn1d_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int
     }
     St st = st1d(ws, pl, l);
     DFA_HIP_CHECK(ctx, launch_cm_stats(z, partial, B, C[l], T, s));
-    DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nch, C[l], (double)B * T, st.mean, st.var, st.invstd,
-                                          update_running_stats ? (float*)q[4] : nullptr,
-                                          update_running_stats ? (float*)q[5] : nullptr, momentum, s));
+    { const int rc = finalize_bn_stats(ctx, partial, nch, C[l], (double)B * T, st.mean, st.var, st.invstd,
+                                       update_running_stats ? (float*)q[4] : nullptr, update_running_stats ? (float*)q[5] : nullptr, momentum, nullptr);
+      if (rc != DFA_OK) return rc; }
     if (l < 2) {
       dc.layer = 1 + l;
       DFA_HIP_CHECK(ctx, launch_cm_bn_relu_drop(z, st.mean, st.invstd, q[2], q[3], (float*)(ws + pl.h[l]), B, C[l], T, dc, s));
@@ -612,7 +612,7 @@ int dfa_cnn1d_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, i
     const float* up = (l == 2) ? dpooled : (const float*)(ws + pl.dh[l]);
     dc.layer = 1 + l;
     DFA_HIP_CHECK(ctx, launch_cm_bn_bwd(l == 2 ? 0 : 1, (const float*)(ws + pl.z[l]), st.mean, st.invstd, q[2], q[3], up, partial, sm, dz,
-                                        B, C[l], T, dc, s));
+                                        B, C[l], T, dc, s, ctx->bn_sync.fn ? &ctx->bn_sync : nullptr));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(128), 0, s, sm, grads[4 * l + 2], grads[4 * l + 3], C[l]);
     if (l == 0) {
       DFA_HIP_CHECK(ctx, launch_conv1d_wgrad(dz, (const float*)x, stride_b, stride_f, stride_t, partial, grads[0], grads[1], B, F, 32, T, s,

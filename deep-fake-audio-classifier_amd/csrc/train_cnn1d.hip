@@ -407,10 +407,10 @@ hipError_t launch_cm_bn_relu_meant(const float* z, const float* mean, const floa
 }
 hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, const float* up, float* partial, float* sums, float* dz, int B, int C,
-                            int T, const DropCfg& dc, hipStream_t s) {
+                            int T, const DropCfg& dc, hipStream_t s, const BnSync* sync) {
   const int nch = cm_chunks(B), bchunk = (B + nch - 1) / nch;
   const size_t n = (size_t)B * C * T;
-  const float inv_n = (float)(1.0 / ((double)B * T));
+  float inv_n = (float)(1.0 / ((double)B * T));
   if (src == 0)
     hipLaunchKernelGGL(cm_bn_bwd_reduce_kernel<0>, dim3(C, nch), dim3(256), 0, s, z, mean, invstd, gamma, beta, up, partial, B, C, T, bchunk, dc);
   else
@@ -419,10 +419,15 @@ hipError_t launch_cm_bn_bwd(int src, const float* z, const float* mean, const fl
   if (e != hipSuccess) return e;
   e = launch_reduce_partials(partial, nch, C * 2, 1.0f, sums, s, nullptr);
   if (e != hipSuccess) return e;
+  const float* sums_a;
+  float isc;
+  e = bn_sync_sums(sync, sums, C * 2, s, &sums_a, &isc);          // synchronised BatchNorm: global sums, global count
+  if (e != hipSuccess) return e;
+  inv_n *= isc;
   if (src == 0)
-    hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums, up, dz, C, T, n, inv_n, dc);
+    hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums_a, up, dz, C, T, n, inv_n, dc);
   else
-    hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums, up, dz, C, T, n, inv_n, dc);
+    hipLaunchKernelGGL(cm_bn_bwd_apply_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, mean, invstd, gamma, beta, sums_a, up, dz, C, T, n, inv_n, dc);
   return hipGetLastError();
 }
 // partial: conv1d_wgrad_chunks(B) * (Cout*Cin*3 + Cout) floats

@@ -149,7 +149,7 @@ def parse_args(argv=None):
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     p.add_argument("--native", action="store_true", help="all-native step (fused AdamW, flat-gradient all-reduce)")
     p.add_argument("--sync-bn", action="store_true",
-                   help="data-parallel CNN2D: BatchNorm statistics over the global batch (N ranks x B train like one rank x N*B); "
+                   help="data-parallel training: BatchNorm statistics over the global batch (N ranks x B train like one rank x N*B); "
                         "default: each rank's own statistics, as torch DistributedDataParallel")
     sw = p.add_mutually_exclusive_group()
     sw.add_argument("--swap-tf", dest="swap_tf", action="store_true")
@@ -198,7 +198,7 @@ def main(argv=None):
         from .training.train_step import FlatTrainer, NativeTrainer
         # all-C-ABI step for both classifiers: 464,644-byte (CNN2D) / 195,204-byte (CNN1D) flat gradient, one all-reduce
         trainer = NativeTrainer(model, lr=args.lr, weight_decay=weight_decay, label_smoothing=args.label_smoothing,
-                                sync_bn=bool(getattr(args, "sync_bn", False)) and args.model == "cnn2d" and world > 1)
+                                sync_bn=bool(getattr(args, "sync_bn", False)) and world > 1)
         dfa_dist.broadcast_parameters_(trainer.flat_p)
         dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
         # Flat, memory-mapped sources: a rank reads only the rows it consumes (1 / world of the training set per epoch, its

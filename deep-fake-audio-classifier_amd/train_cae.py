@@ -135,6 +135,9 @@ def parse_args(argv=None):
     p.add_argument("--trainer", default="native", choices=["native", "autograd"],
                    help="native: the whole step on the C ABI (no reconstruction / loss-gradient tensors, fused AdamW); autograd: "
                         "torch criterion + loss.backward() over the C-ABI autograd bridge")
+    p.add_argument("--sync-bn", action="store_true",
+                   help="data-parallel training with the native trainer: BatchNorm statistics over the global batch "
+                        "(default: each rank's own statistics, as torch DistributedDataParallel)")
     return p.parse_args(argv)
 
 
@@ -188,7 +191,8 @@ def main(argv=None):
         # AdamW, equal step counts on every rank
         from .training.train_step import CaeNativeTrainer, FlatTrainer
         Trainer = CaeNativeTrainer if args.trainer == "native" else FlatTrainer
-        optimizer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay)
+        kw = {"sync_bn": True} if (args.sync_bn and world > 1 and args.trainer == "native") else {}
+        optimizer = Trainer(model, lr=args.lr, weight_decay=args.weight_decay, **kw)
         dfa_dist.broadcast_parameters_(optimizer.flat_p)
         scheduler = optimizer.plateau_scheduler(**sched_kw)
     else:

@@ -412,11 +412,9 @@ class NativeTrainer(_FlatAdamW):
             raise ValueError("--label-smoothing must be in [0, 0.5)")          # src/train.py:308-309
         super().__init__(model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, process_group=process_group)
         self.label_smoothing = label_smoothing
-        # sync_bn (CNN2D, world > 1): BatchNorm statistics over the GLOBAL batch (six 2C-float all-reduces per step through the
+        # sync_bn (world > 1): BatchNorm statistics over the GLOBAL batch (two 2C-float all-reduces per layer and step through the
         # C ABI's hook): N ranks x B then train like one rank x N*B; the default is DistributedDataParallel's local statistics
         self.sync_bn = bool(sync_bn)
-        if self.sync_bn and type(model).__name__ != "CNN2D":
-            raise ValueError("sync_bn is implemented for the CNN2D")
         _lib.Context.get(self.flat_p.device).set_bn_sync(process_group, enable=self.sync_bn)
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
         self.dlogits = None
@@ -452,8 +450,10 @@ class CaeNativeTrainer(_FlatAdamW):
     (dfa_cae_backward with drecon = NULL) and writes the 30 gradients straight into the flat buffer, then ONE 2,246,532-byte
     all-reduce and the fused AdamW.  No reconstruction, no loss gradient, no autograd graph and no torch elementwise kernel."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, process_group=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, process_group=None, sync_bn=False):
         super().__init__(model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, process_group=process_group)
+        self.sync_bn = bool(sync_bn)      # BatchNorm statistics over the global batch (NativeTrainer's docstring)
+        _lib.Context.get(self.flat_p.device).set_bn_sync(process_group, enable=self.sync_bn)
 
     def step(self, x):
         """One optimisation step on the (z-scored) batch x[B,T,F]; returns the device scalar MSELoss(recon, x) of this rank."""

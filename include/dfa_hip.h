@@ -191,16 +191,17 @@ int dfa_cnn2d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shif
 int dfa_cnn1d_set_train_augment(dfa_ctx* ctx, int enable, int T, int F, int shift, const float* keep_f, int tmask_start,
                                 int tmask_len, int fmask_start, int fmask_len, float jitter_std, uint64_t seed,
                                 uint64_t offset);
-/* Synchronised BatchNorm for data-parallel CNN2D training (the optional `dfa_bn_stats_{get,set}` pair, as
+/* Synchronised BatchNorm for data-parallel training of all three models (the optional `dfa_bn_stats_{get,set}` pair, as
  * ONE hook): the reference trains on one GPU with plain BatchNorm2d (src/model.py:16,22,28); N ranks x B utterances reproduce one
  * rank x N*B -- statistics, running statistics and gradients, up to summation order -- when every BatchNorm layer's per-channel sums
  * are added over the ranks between their reduction and their use: (sum x, sum x^2) in the forward, (sum dy, sum dy*xhat) in the
- * backward, 2*C floats each, six exchanges per step.  With a hook set, dfa_cnn2d_forward_train / dfa_cnn2d_backward copy those sums
- * into `buf` (caller-owned DEVICE memory, >= 256 floats) and call fn(user, buf, count) on the calling thread; fn enqueues an in-place
+ * backward, 2*C floats each, six exchanges per step for the classifiers, fourteen for the auto-encoder.  With a hook set, the
+ * forward_train / backward entry points copy those sums into `buf` (caller-owned DEVICE memory, >= 512 floats) and call fn(user, buf, count) on the calling thread; fn enqueues an in-place
  * SUM all-reduce of buf[0 .. count) ordered after the work already on the context's stream (torch.distributed.all_reduce on the
  * tensor that owns buf does) and returns 0.  dgamma / dbeta stay the rank's own sums: the flat-gradient all-reduce adds them.
- * Block 1 then runs the two-pass vector backward (the one-pass moment algebra needs the sums too late).  fn = NULL: local statistics
- * (torch DistributedDataParallel's default; what dfa_amd.train uses unless --sync-bn is given).  CNN2D only. */
+ * Block 1 of the CNN2D / auto-encoder then runs the two-pass vector backward (the one-pass moment algebra needs the sums too late).
+ * fn = NULL: local statistics (torch DistributedDataParallel's default; what dfa_amd.train / train_cae use unless --sync-bn is given).
+ * Set it before a forward_train; it stays in force until changed. */
 typedef int (*dfa_bn_sync_fn)(void* user, float* buf, int count);
 int dfa_ctx_set_bn_sync(dfa_ctx* ctx, dfa_bn_sync_fn fn, void* user, int world, float* buf, int capacity);
 /* one torch.optim.AdamW step over a flat fp32 buffer: p *= 1-lr*wd; m,v update; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).
