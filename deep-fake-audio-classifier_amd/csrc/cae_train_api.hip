@@ -170,9 +170,18 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
   for (int hlf = 0; hlf < 2; ++hlf)
     DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[18], p[19], nullptr, nullptr, nullptr, nullptr, 128, 64 * hlf, 64, 256, prec,
                                                 m.tenc[2].wpack + (size_t)hlf * (256 / 32) * 9 * nkg * 64, m.tenc[2].bias, s, 0));
+  // bf16 mode: the 64 -> 32 and 128 -> 64 data gradients on the 16x16x32 kernels of conv_split.hip, one launch each (as the CNN2D's;
+  // the 32x32x16 forms ran the first with one channel slice per workgroup -- 0.31 ms -- and the second as two launches chained
+  // through fp32 partial sums)
+  m.train_dgrad_m16 = (prec == DFA_PREC_BF16 && ctx->dgrad_m16) ? 1 : 0;
+  if (m.train_dgrad_m16) {
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad_m16(p[6], 32, 64, m.tdg[0].wpack, m.tdg[0].bias, s));
+    DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad_m16(p[12], 64, 128, m.tdg[1].wpack, m.tdg[1].bias, s));
+  } else {
   DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[6], 32, 64, 0, 64, prec, m.tdg[0].wpack, m.tdg[0].bias, s));
   for (int hlf = 0; hlf < 2; ++hlf)
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64 * hlf, 64, prec, m.tdg[1].wpack + (size_t)hlf * (64 / 32) * 9 * nkg * 64, m.tdg[1].bias, s));
+  }
   for (int c = 0; c < 4; ++c)
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[18], 128, 256, 64 * c, 64, prec, m.tdg[2].wpack + (size_t)c * (128 / 32) * 9 * nkg * 64, m.tdg[2].bias, s));
   for (int l = 0; l < 3; ++l) {
@@ -342,7 +351,8 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     a.in = ws + pl.dz[l]; a.wpack = m.tdg[l - 1].wpack; a.bias = m.tdg[l - 1].bias; a.out = ws + pl.de[l - 1];
     a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l - 1]; a.relu = 0; a.zero_page = ctx->zero_page;
     hipError_t e = (l == 3) ? launch_cae_dgrad4(prec, a, (float*)(ws + pl.raw), s)
-                 : (l == 2) ? launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s) : launch_train_dgrad2(prec, a, s);
+                 : (l == 2) ? (m.train_dgrad_m16 ? launch_train_dgrad3_m16(a, s, train_conv_variant() != 0) : launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s))
+                            : (m.train_dgrad_m16 ? launch_train_dgrad2_m16(a, s, train_conv_variant() != 0) : launch_train_dgrad2(prec, a, s));
     DFA_HIP_CHECK(ctx, e);
   }
   // ---- encoder block 1 (z1 recomputed from x; upstream through the 2x2 average pool)

@@ -107,6 +107,7 @@ struct CaeState {
   void* train_packed = nullptr;
   float *tw1 = nullptr, *tb1 = nullptr;
   int train_c1_mfma = 0;       // this step's block-1 passes run on the matrix cores (train_conv1_mfma.hip, 2x2-pool backward)
+  int train_dgrad_m16 = 0;     // this step's 64 -> 32 and 128 -> 64 data-gradient images are in the 16x16x32 order of conv_split.hip (bf16 mode)
   PackedConv tenc[3], tdg[3], tdec[3];
   int train_prec = -1, train_B = 0, train_T = 0;
 };
