@@ -5,17 +5,17 @@
 // ~80 cycles per 2048 MACs by the fp32 matrix pipe (2172 MFMAs = 174 k cycles per utterance, 85 us per 256 utterances); the same
 // MACs cost 3 x 32 cycles per 16384 here, so the kernel is bound by moving and splitting x instead.
 //   * workgroup = one utterance, 8 waves (two per SIMD); x is read ONCE with aligned 16-byte loads: the reference stores [F][T] contiguously
-//     (src/dataset.py:52), so 16 input channels = one contiguous, 16-byte aligned slab of 16 T floats; slabs are double-buffered
-//     in LDS as they are (fp32, [channel][frame]) and the lane that owns frame t reads x[c][t-1 .. t+1] for its 8 channels as
-//     conflict-free ds_read_b32 -- the three conv taps of a k-step from one set of reads;
-//   * the values are split into hi / lo bf16 in registers and ARE the B fragments (lane = frame, 8 consecutive channels per
-//     lane half): layer 1 needs no transposed image at all.  Its weights (72 KB of A fragments) sit in LDS for the layer;
+//     (src/dataset.py:52), so 16 input channels = one contiguous, 16-byte aligned slab of 16 T floats; a slab passes through LDS as
+//     it is (fp32, [channel][frame]) and is split ONCE into a pixel image [frame + 1][hi 16 ch | lo 16 ch] (bf16, 64 bytes per frame,
+//     swizzled, zero halo): the lane that owns frame t reads the B fragments of its three taps as two ds_read_b128 each (the layer-1
+//     comment in the kernel has the pipeline);
+//   * its weights (72 KB of A fragments) sit in LDS for the layer;
 //   * h1 [T][32] and h2 [T][64] live in LDS channels-last as [hi: C bf16][lo: C bf16] pixels with the chunk swizzle of
 //     conv3x3_mfma.h, written from the accumulator layout as 8-byte stores (4 consecutive channels of one frame per lane),
 //     read as ds_read_b128 fragments at frame t + tap - 1; layers 2 and 3 keep their hi / lo A fragments in registers;
 //   * frame mean and the 128 -> 1 classifier in the epilogue, as in cnn1d_fused.hip: logits[b] is the only global write.
-// LDS: region A = two x slabs during layer 1, then h1; region B = layer-1 weights, then h2 (136 KB at T = 321).
-// Takes the reference's storage only (x[b][f][t] contiguous, 16-byte aligned, F % 4 == 0, 3 <= T <= 384); anything else runs
+// LDS: two fp32 slabs + two split images + layer-1 weights during layer 1 (156.5 KB at T = 321), then h1 and h2 over the same space.
+// Takes the reference's storage only (x[b][f][t] contiguous, 16-byte aligned, F % 4 == 0, 3 <= T <= 347 at F = 180: the LDS budget); anything else runs
 // cnn1d_fused.hip / the three-launch path (api.hip).
 #include "dfa_internal.h"
 #include "conv3x3_mfma.h"
@@ -65,7 +65,8 @@ struct Cnn1dX3Args {
   const float *b1, *b2, *b3, *cw, *cb;
   float* logits;
   int T, F, NT, nks1;          // NT = ceil(T / 32), nks1 = ceil(F / 16)
-  int offA_h1, offB;           // LDS byte offsets: region A = [0, offB) (slabs / h1), region B = [offB, ...) (W1 / h2)
+  int offA_h1, offB;           // LDS byte offsets: [0, offS) two fp32 slabs, [offS, offB) two split images, [offB, ...) layer-1 weights;
+  int offS, offH2;             // after layer 1: h1 at 0, h2 at offH2
   int slab_floats;             // 16 T + 8
   long long* stamps;
 };
@@ -162,32 +163,39 @@ __global__ __launch_bounds__(512) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
   float* const slab0 = (float*)smem;                      // two slabs of slab_floats floats: [4 pad][16 x T][4 pad]
   char* const h1S = smem;                                 // region A again, after layer 1: [nslots][128 B]
   char* const w1S = smem + a.offB;                        // region B: layer-1 A fragments [3][nks1][2][64] x 16 B ...
-  char* const h2S = smem + a.offB;                        // ... then h2 [nslots][256 B]
-  float* const red = (float*)(smem + a.offB + nslots * 256);
+  char* const h2S = smem + a.offH2;                       // h2 [nslots][256 B]: behind h1, over the (then dead) slab / weight regions
+  float* const red = (float*)(smem + a.offH2 + nslots * 256);
   const bool stamp = a.stamps != nullptr && tid == 0 && b < 128;
   if (stamp) { a.stamps[8 * b] = __builtin_amdgcn_s_memtime(); a.stamps[8 * b + 5] = __builtin_amdgcn_s_memrealtime(); }
 
   // ------------------------------------------------------------------------------------------------ layer 1: F -> 32
+  // A slab (16 channels x T frames, fp32, contiguous) goes global -> registers -> LDS as it is (F buffers), is then SPLIT ONCE
+  // into a pixel image S[slot = frame + 1][hi: 16 ch bf16 | lo: 16 ch bf16] (64 bytes per frame, the chunk swizzle of the
+  // h1 / h2 images; halo slots and the slots beyond T stay zero), and the tiles read their three taps from that image as two
+  // ds_read_b128 each.  The first version split x[c][t-1..t+1] per lane and tap -- every element three times, plus six masks per
+  // tile -- and layer 1 was bound by that vector work (51 k of the kernel's 86 k cycles for 13.8 k cycles of matrix-pipe time).
+  // Pipeline per trip s (one barrier): compute slab s from S[s & 1] | split slab s + 1: F[(s+1) & 1] -> S[(s+1) & 1] | park slab
+  // s + 2 (registers) in F[s & 1] | request slab s + 4.
   const int nks1 = a.nks1;
   f32x16_t acc1[MAXT1];
   {
     const float4* xg = (const float4*)(a.x + (size_t)b * a.F * T);
     const int SL = a.slab_floats;
+    char* const S0 = smem + a.offS;                          // two split images of nslots x 64 bytes
+    const int SB = nslots * 64;
     constexpr int NLD = 3;                                   // 16 T / 4 float4 per slab <= 1536 = 3 x 512
-    float4 xrA[NLD], xrB[NLD];                                // two slabs in flight: a slab has two loop trips (~4 k cycles) to land
-    // Loads are unconditional (clamped index) and the zero fill of a short last slab happens at store time: a conditional load is
-    // an exec branch, and hipcc's vmcnt bookkeeping across a branch is conservative (seen in the ISA: vmcnt(0) behind every load).
+    float4 xrA[NLD], xrB[NLD];                                // even / odd slabs in flight
     const int nreal = (a.F + 15) / 16;                        // slabs that exist (nks1 may be one more: a zero slab)
     auto slab_n4 = [&](int s) { return max(0, min(16, a.F - 16 * s)) * T / 4; };
-    auto slab_load = [&](int s, float4 (&xr)[NLD]) {          // slab s = channels 16 s .. (one contiguous run of rows * T floats)
-      const int sc = min(s, nreal - 1), n4 = slab_n4(sc);
+    auto slab_load = [&](int s, float4 (&xr)[NLD]) {          // unconditional, clamped index (a conditional load is an exec branch
+      const int sc = min(s, nreal - 1), n4 = slab_n4(sc);    //  and hipcc's vmcnt bookkeeping across a branch is conservative)
       const float4* src = xg + (size_t)4 * sc * T;
 #pragma unroll
       for (int k = 0; k < NLD; ++k) xr[k] = src[min(k * NTH + tid, n4 - 1)];
     };
-    auto slab_store = [&](int s, const float4 (&xr)[NLD]) {
+    auto slab_park = [&](int s, const float4 (&xr)[NLD]) {    // registers -> F[s & 1]; channels a short / padded slab lacks become zeros
       float* dst = slab0 + (s & 1) * SL + 4;
-      const int n4 = slab_n4(s);                              // channels a short (or padded) last slab does not have become zeros
+      const int n4 = slab_n4(s);
 #pragma unroll
       for (int k = 0; k < NLD; ++k) {
         const int i = k * NTH + tid;
@@ -197,79 +205,93 @@ __global__ __launch_bounds__(512) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
           *(uint4*)(dst + 4 * i) = make_uint4(__float_as_uint(v.x) & m, __float_as_uint(v.y) & m, __float_as_uint(v.z) & m, __float_as_uint(v.w) & m);
       }
     };
+    auto slab_split = [&](int s) {                            // F[s & 1] -> S[s & 1]: item = (frame t, channel octet g), lanes run along t
+      const float* fb = slab0 + (s & 1) * SL + 4;
+      char* sb = S0 + (s & 1) * SB;
+      // 2 T <= 768 items: one per thread, the remaining 2 T - 512 go to the waves that own ONE frame tile (waves NT - 8 ...: the
+      // first NT - 8 waves carry two tiles per trip and would otherwise also carry two items -- every trip ends in a barrier)
+      const int t2 = tid - 64 * max(0, NT - NW);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int it = pass == 0 ? tid : (t2 >= 0 ? NTH + t2 : 2 * T);
+        if (it < 2 * T) {
+          const int g = it >= T ? 1 : 0, t = it - g * T;
+          float v[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = fb[(8 * g + c) * T + t];
+          uint4 hi, lo;
+          split8(v, hi, lo);
+          const int slot = t + 1, sw = lds_swz<64>(slot);
+          *(uint4*)(sb + slot * 64 + ((g ^ sw) << 4)) = hi;
+          *(uint4*)(sb + slot * 64 + (((2 + g) ^ sw) << 4)) = lo;
+        }
+      }
+    };
     slab_load(0, xrA);
     slab_load(1, xrB);
-    // layer-1 A fragments -> LDS (contiguous copy), pads of the two slabs
+    // layer-1 A fragments -> LDS (contiguous copy); the never-written slots of both split images (0 and T + 1 ...) -> zero
     {
       const int n = 3 * nks1 * 2 * 64;
       for (int i = tid; i < n; i += NTH) *(uint4*)(w1S + (size_t)i * 16) = a.w1[i];
-      if (tid < 16) {
-        const int sb = tid >> 3, e = tid & 7;
-        slab0[sb * SL + (e < 4 ? e : 16 * T + e)] = 0.f;
+      const int nz = (nslots - T) * 4;                        // 16-byte chunks of the zero slots, per image
+      for (int i = tid; i < 2 * nz; i += NTH) {
+        const int img = i >= nz, q = i - img * nz, zs = q >> 2;
+        const int slot = zs == 0 ? 0 : T + zs;
+        *(uint4*)(S0 + img * SB + slot * 64 + (q & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    slab_store(0, xrA);
+    slab_park(0, xrA);
+    slab_load(2, xrA);
+    __syncthreads();
+    slab_split(0);
+    slab_park(1, xrB);
+    slab_load(3, xrB);
     __syncthreads();
 
     const int nmine = (NT - wave + NW - 1) / NW;
-    unsigned tin[MAXT1][3];                                  // all-ones where tap k of this lane's frame exists, else 0
-    int tl[MAXT1];
 #pragma unroll
-    for (int j = 0; j < MAXT1; ++j) {
-      const int t = TW * (wave + NW * j) + col;
-      tl[j] = t;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) tin[j][k] = ((j < nmine) && t < T && t - 1 + k >= 0 && t - 1 + k < T) ? 0xffffffffu : 0u;
+    for (int j = 0; j < MAXT1; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-    }
-    // one slab = one k-step of 16 channels: trip s computes slab s from buffer s & 1, requests slab s + 2 and parks slab s + 1
-    // (requested a trip ago) in the other buffer; one barrier per trip
-    auto trip = [&](int s, float4 (&xr_next)[NLD], float4 (&xr_far)[NLD], bool load) {
-      if (load) slab_load(s + 2, xr_far);                     // (compile-time after inlining: the steady loop loads, the two tail trips do not)
-      const float* sl = slab0 + (s & 1) * SL + 4 + 8 * h * T - 1;       // this lane half's 8 channels, frame index - 1
+    auto trip = [&](int s, float4 (&xr)[NLD]) {               // xr: the register set of this trip's parity (holds slab s + 2)
+      const char* sb = S0 + (s & 1) * SB;
       uint4 wh[3], wl[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         wh[k] = *(const uint4*)(w1S + ((size_t)((k * nks1 + s) * 2) * 64 + lane) * 16);
         wl[k] = *(const uint4*)(w1S + ((size_t)((k * nks1 + s) * 2 + 1) * 64 + lane) * 16);
       }
-      float va[3][8], vb[3][8];
-      auto rdv = [&](int j, float (&v)[3][8]) {
+      uint4 xh[MAXT1][3], xl[MAXT1][3];
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-          for (int k = 0; k < 3; ++k) v[k][c] = sl[c * T + tl[j] + k];
-      };
-      auto mm = [&](int j, const float (&v)[3][8]) {
+      for (int j = 0; j < MAXT1; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          uint4 xh, xl;
-          split8(v[k], xh, xl);
-          xh = and4(tin[j][k], xh);
-          xl = and4(tin[j][k], xl);
-          acc1[j] = mma_bf16(wh[k], xh, acc1[j]);
-          acc1[j] = mma_bf16(wl[k], xh, acc1[j]);
-          acc1[j] = mma_bf16(wh[k], xl, acc1[j]);
+          const int slot = min(TW * (wave + NW * j) + col + k, nslots - 1);      // (tiles this wave does not have: clamped, unused)
+          const int sw = lds_swz<64>(slot);
+          xh[j][k] = *(const uint4*)(sb + slot * 64 + ((h ^ sw) << 4));
+          xl[j][k] = *(const uint4*)(sb + slot * 64 + (((2 + h) ^ sw) << 4));
         }
-      };
-      rdv(0, va);
       __builtin_amdgcn_sched_barrier(0);
-      rdv(1, vb);
-      mm(0, va);
+#pragma unroll
+      for (int j = 0; j < MAXT1; ++j)
+        if (j < nmine) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            acc1[j] = mma_bf16(wh[k], xh[j][k], acc1[j]);
+            acc1[j] = mma_bf16(wl[k], xh[j][k], acc1[j]);
+            acc1[j] = mma_bf16(wh[k], xl[j][k], acc1[j]);
+          }
+        }
       __builtin_amdgcn_sched_barrier(0);
-      mm(1, vb);
-      __builtin_amdgcn_sched_barrier(0);
-      slab_store(s + 1, xr_next);
+      slab_split(s + 1);                                      // (past the last slab: a stale buffer into an image nobody reads)
+      slab_park(s + 2, xr);
+      slab_load(s + 4, xr);                                   // (clamped: past the end it re-reads the last slab, never parked as data)
       __syncthreads();
     };
-    int s = 0;
-    for (; s + 2 < nks1; s += 2) {                            // nks1 is even: no branch in the steady loop
-      trip(s, xrB, xrA, true);
-      trip(s + 1, xrA, xrB, true);
+    for (int s = 0; s < nks1; s += 2) {                       // nks1 is even
+      trip(s, xrA);
+      trip(s + 1, xrB);
     }
-    trip(s, xrB, xrA, false);
-    trip(s + 1, xrA, xrB, false);
   }
   if (stamp) a.stamps[8 * b + 1] = __builtin_amdgcn_s_memtime();
   // (the barrier that closed the loop: every wave is done with the slabs and the layer-1 weights)
@@ -373,14 +395,17 @@ __global__ __launch_bounds__(512) void cnn1d_fused_x3_kernel(Cnn1dX3Args a) {
   if (tid == 0) a.logits[b] = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) + a.cb[0];
 }
 
-static void cnn1d_x3_layout(int T, int F, int* offB, int* total, int* slab_floats) {
+static void cnn1d_x3_layout(int T, int F, int* offB, int* total, int* slab_floats, int* offS = nullptr, int* offH2 = nullptr) {
   const int NT = (T + 31) / 32, nslots = 32 * NT + 2, nks1 = cnn1d_x3_nks(F);
   const int SL = 16 * T + 8;
-  const int regA = std::max(2 * SL * 4, nslots * 128);
-  const int regB = std::max(3 * nks1 * 2 * 64 * 16, nslots * 256);
-  *offB = (regA + 255) / 256 * 256;
-  *total = *offB + regB + 64;
+  const int oS = (2 * SL * 4 + 255) / 256 * 256;                       // two fp32 slabs
+  const int oB = (oS + 2 * nslots * 64 + 255) / 256 * 256;             // two split images
+  const int oH2 = (nslots * 128 + 255) / 256 * 256;                    // h1, then h2
+  *offB = oB;
+  *total = std::max(oB + 3 * nks1 * 2 * 64 * 16, oH2 + nslots * 256 + 64);
   *slab_floats = SL;
+  if (offS) *offS = oS;
+  if (offH2) *offH2 = oH2;
 }
 // x must be the contiguous [B][F][T] storage (element (b, t, f) at b F T + f T + t), 16-byte aligned
 // ---- one Conv1d(k = 3, pad 1) layer of the TRAINING step on the matrix cores (src/train.py:71-76 through
@@ -727,7 +752,7 @@ hipError_t launch_cnn1d_fused_x3(const float* x, const void* w1, const float* b1
   a.x = x; a.w1 = (const uint4*)w1; a.w2 = (const uint4*)w2; a.w3 = (const uint4*)w3; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.cw = cw; a.cb = cb;
   a.logits = logits; a.T = T; a.F = F; a.NT = (T + 31) / 32; a.nks1 = cnn1d_x3_nks(F); a.stamps = stamps;
   int total;
-  cnn1d_x3_layout(T, F, &a.offB, &total, &a.slab_floats);
+  cnn1d_x3_layout(T, F, &a.offB, &total, &a.slab_floats, &a.offS, &a.offH2);
   hipError_t e = hipFuncSetAttribute((const void*)cnn1d_fused_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cnn1d_fused_x3_kernel, dim3(B), dim3(c1x::NTH), total, s, a);
