@@ -69,6 +69,15 @@ __global__ __launch_bounds__(256) void cae_enc1_mfma_kernel(const TX* __restrict
   const int t_base = 2 * q0 - 1;
   const bool t_fast = (st == 1);
   const int ncol = F + 2;
+  float* const zs = xs + XR * pitch;                  // [F][2]: 1 / sigma, -mu / sigma (z-score table, only when mu != null)
+  if (mu) {
+    for (int f = tid; f < F; f += 256) {
+      const float rs = __builtin_amdgcn_rcpf(sigma[f]);
+      zs[2 * f] = rs;
+      zs[2 * f + 1] = -mu[f] * rs;
+    }
+    __syncthreads();
+  }
   // Eight loads in flight per thread and trip (a one-load-per-trip loop pays the memory latency 25 times per workgroup: the
   // vector kernel it replaces does, and so did the first version of this one -- 0.158 ms for 0.06 ms of arithmetic).
   constexpr int NE = 8;
@@ -86,10 +95,10 @@ __global__ __launch_bounds__(256) void cae_enc1_mfma_kernel(const TX* __restrict
       const TX* p = xb + (ok ? (int64_t)t * st + (int64_t)f * sf : 0);      // clamped address, branch-free
       float xv;
       if constexpr (sizeof(TX) == 2) xv = bf16_to_float(*p); else xv = *p;
-      // z-score as (x - mu) * rcp(sigma): v_rcp_f32 + one multiply instead of an IEEE division (~10 instructions per element of a
-      // kernel that is bound by its vector ALU); the 1-2 ulp difference disappears in the bf16 rounding of the operand (bf16 mode only:
-      // the fp32 parity path keeps the division)
-      if (mu) { const int fc = ok ? f : 0; xv = (xv - mu[fc]) * __builtin_amdgcn_rcpf(sigma[fc]); }
+      // z-score as x * (1 / sigma) - mu / sigma from a per-column table in LDS (built once per workgroup): one LDS read pair + one FMA
+      // per element instead of two more global loads and an IEEE division (this loop is bound by its memory instructions); the 1-2
+      // ulp difference disappears in the bf16 rounding of the operand (bf16 mode only: the fp32 parity path keeps the division)
+      if (mu) { const int fc = ok ? f : 0; xv = fmaf(xv, zs[2 * fc], zs[2 * fc + 1]); }
       v[k] = ok ? xv : 0.f;                     // the convolution's zero padding applies to the NORMALISED input
       dst[k] = e < nel ? rr * pitch + cc : -1;
     }
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void cae_enc1_mfma_kernel(const TX* __restrict
 }
 
 int cae_enc1_mfma_pitch(int F) { return (F + 2 + 31) / 32 * 32 + 1; }
-size_t cae_enc1_mfma_lds(int F) { return (size_t)e1m::XR * cae_enc1_mfma_pitch(F) * sizeof(float); }
+size_t cae_enc1_mfma_lds(int F) { return ((size_t)e1m::XR * cae_enc1_mfma_pitch(F) + 2 * (size_t)F) * sizeof(float); }   // x rows + the z-score table
 
 hipError_t launch_cae_enc1_mfma(const void* x, int x_dtype, int64_t sb, int64_t st, int64_t sf, const float* mu, const float* sigma,
                                 const uint4* c1pack, const float* c1bias, void* out, int B, int T, int F, hipStream_t s) {
