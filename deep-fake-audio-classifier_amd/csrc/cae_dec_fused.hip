@@ -50,7 +50,9 @@ constexpr int LAT_B = NP * 512, D1_B = 4 * NP * 256;
 constexpr int B2_OFF = LAT_B + D1_B;         // [64] float: block 2's folded bias (read per unit; global loads there would serialise)
 constexpr int W3_OFF = B2_OFF + 256;         // [4 q3][4 k-steps][64 lanes] x 16 B: block 3's fragments in the permuted channel order
 constexpr int RED_OFF = W3_OFF + 16384;      // [8] float
-constexpr int LDS_BYTES = RED_OFF + 64;
+constexpr int ZS_OFF = RED_OFF + 64;          // [F <= 1024][2] float: 1 / sigma, -mu / sigma (z-score table of the NORM instantiations)
+constexpr int ZS_MAXF = 1024;
+constexpr int LDS_BYTES = ZS_OFF + 2 * ZS_MAXF * 4;
 }  // namespace cdf
 
 __device__ __forceinline__ float cdf_ldx(const CaeDecFusedArgs& a, int b, int t, int f) {
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a
   char* const latS = smem;
   char* const d1S = smem + LAT_B;
   float* const red = (float*)(smem + RED_OFF);
+  const float* const zsS = (const float*)(smem + ZS_OFF);
   float* const b2S = (float*)(smem + B2_OFF);
   const uint4* const w3S = (const uint4*)(smem + W3_OFF);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -130,6 +133,14 @@ __global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a
     for (int it = 0; it < 2; ++it)
       *(uint4*)(smem + W3_OFF + ((((tid >> 6) + 8 * it) * 64 + lane) << 4)) = make_uint4(e[it][0].x, e[it][0].y, e[it][1].x, e[it][1].y);
     if (tid < 64) b2S[tid] = b2v;
+    if constexpr (NORM) {                          // z-score table: x_hat = x * zs[f][0] + zs[f][1]
+      float* zs = (float*)(smem + ZS_OFF);
+      for (int f = tid; f < a.F; f += 512) {
+        const float rs = __builtin_amdgcn_rcpf(a.sigma[f]);   // (v_rcp_f32: the error term is fp32, 1-2 ulp are far below the 2e-5 score tolerance)
+        zs[2 * f] = rs;
+        zs[2 * f + 1] = -a.mu[f] * rs;
+      }
+    }
   }
   __syncthreads();
   if (stamp) a.stamps[8 * sid + 1] = __builtin_amdgcn_s_memtime();
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a
           for (int c = 0; c < 2; ++c) xr[mt][c] = cdf_ldraw<XBF>(xu, o0 + 2u * (mt >> 1) * ust + (2u * (mt & 1) + c) * usf);
         if constexpr (NORM) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { mu4[c] = a.mu[fq + c]; sg4[c] = __builtin_amdgcn_rcpf(a.sigma[fq + c]); }   // 1 / sigma (v_rcp_f32: the error term is fp32, 1-2 ulp are far below the 2e-5 score tolerance)
+          for (int c = 0; c < 4; ++c) { sg4[c] = zsS[2 * (fq + c)]; mu4[c] = zsS[2 * (fq + c) + 1]; }      // LDS table (global loads here would wait)
         }
       }
       uint4 dk[4];
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void cae_dec_fused_kernel(CaeDecFusedArgs a
         const float r0 = y[0] + b4, r1 = y[1] + b4;
         if (valid) {
           float x0 = xr[mt][0], x1 = xr[mt][1];
-          if constexpr (NORM) { x0 = (x0 - mu4[2 * (mt & 1)]) * sg4[2 * (mt & 1)]; x1 = (x1 - mu4[2 * (mt & 1) + 1]) * sg4[2 * (mt & 1) + 1]; }
+          if constexpr (NORM) { x0 = fmaf(x0, sg4[2 * (mt & 1)], mu4[2 * (mt & 1)]); x1 = fmaf(x1, sg4[2 * (mt & 1) + 1], mu4[2 * (mt & 1) + 1]); }
           const float d0 = r0 - x0, d1 = r1 - x1;
           err = fmaf(d0, d0, err);
           err = fmaf(d1, d1, err);
@@ -378,7 +389,7 @@ hipError_t launch_cae_opad_consts(const float* b2, const uint4* wp3, const float
 
 // the kernel addresses x inside one utterance with unsigned 32-bit element offsets
 bool cae_dec_fused_supports(int T, int F, int64_t st, int64_t sf) {
-  return st >= 0 && sf >= 0 && (int64_t)(T - 1) * st + (int64_t)(F - 1) * sf < ((int64_t)1 << 31);
+  return st >= 0 && sf >= 0 && F <= cdf::ZS_MAXF && (int64_t)(T - 1) * st + (int64_t)(F - 1) * sf < ((int64_t)1 << 31);
 }
 
 int cae_dec_fused_tiles(int H4, int W4) { return (H4 * W4 + cdf::NP - 1) / cdf::NP; }
