@@ -61,9 +61,44 @@ class FlatBatcher:
         self.lo, self.hi = min(rank * per, n), min((rank + 1) * per, n)
         self.features, self.labels = features, labels
         self.batch_size, self.device, self.dtype = batch_size, torch.device(device), dtype
+        self._registered = None
 
     def __len__(self):
         return -(-(self.hi - self.lo) // self.batch_size)
+
+    # A pageable source (the memory-mapped flat file) makes every H2D copy block the host for its duration, so the next forward
+    # is launched only after the next batch's copy has finished (measured 0.85 ms per 256-utterance batch for 0.67 ms of kernels).
+    # Registering this rank's share of the mapping with the HIP runtime (hipHostRegister: the pages are pinned where they are, no
+    # staging copy) makes the copies asynchronous; above `max_register_bytes` (or if the runtime refuses) the pageable path stays.
+    max_register_bytes = 16 << 30
+
+    def _register(self):
+        f = self.features
+        if self._registered is not None or self.device.type != "cuda" or f.device.type != "cpu" or f.is_pinned() or self.hi <= self.lo:
+            return
+        try:
+            if not f[self.lo:self.hi].is_contiguous():
+                return
+            ptr = f[self.lo:self.hi].data_ptr()
+            nbytes = (self.hi - self.lo) * f[0].numel() * f.element_size()
+            if nbytes > self.max_register_bytes:
+                return
+            if int(torch.cuda.cudart().cudaHostRegister(ptr, nbytes, 0)) == 0:
+                self._registered = ptr
+        except Exception:   # noqa: BLE001 -- an optimisation only
+            self._registered = None
+
+    def _unregister(self):
+        if self._registered is not None:
+            try:
+                torch.cuda.synchronize(self.device)
+                torch.cuda.cudart().cudaHostUnregister(self._registered)
+            except Exception:   # noqa: BLE001
+                pass
+            self._registered = None
+
+    def __del__(self):
+        self._unregister()
 
     def _put(self, lo, hi, stream):
         with torch.cuda.stream(stream):
@@ -81,19 +116,23 @@ class FlatBatcher:
                 hi = min(lo + self.batch_size, self.hi)
                 yield self.features[lo:hi], (None if self.labels is None else self.labels[lo:hi])
             return
+        self._register()
         copy_stream = torch.cuda.Stream(self.device)
         starts = list(range(self.lo, self.hi, self.batch_size))
         nxt = self._put(starts[0], min(starts[0] + self.batch_size, self.hi), copy_stream) if starts else None
-        for i, lo in enumerate(starts):
-            f, l, ev = nxt
-            if i + 1 < len(starts):
-                nlo = starts[i + 1]
-                nxt = self._put(nlo, min(nlo + self.batch_size, self.hi), copy_stream)
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            f.record_stream(torch.cuda.current_stream(self.device))
-            if l is not None:
-                l.record_stream(torch.cuda.current_stream(self.device))
-            yield f, l
+        try:
+            for i, lo in enumerate(starts):
+                f, l, ev = nxt
+                if i + 1 < len(starts):
+                    nlo = starts[i + 1]
+                    nxt = self._put(nlo, min(nlo + self.batch_size, self.hi), copy_stream)
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                f.record_stream(torch.cuda.current_stream(self.device))
+                if l is not None:
+                    l.record_stream(torch.cuda.current_stream(self.device))
+                yield f, l
+        finally:
+            self._unregister()
 
 
 class IndexedFlatBatcher:
