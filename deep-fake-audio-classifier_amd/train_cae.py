@@ -135,6 +135,11 @@ def parse_args(argv=None):
     p.add_argument("--trainer", default="native", choices=["native", "autograd"],
                    help="native: the whole step on the C ABI (no reconstruction / loss-gradient tensors, fused AdamW); autograd: "
                         "torch criterion + loss.backward() over the C-ABI autograd bridge")
+    p.add_argument("--flat-input", action="store_true",
+                   help="one GPU: read the features through the flat memory-mapped file + row-gather loader of the data-parallel path "
+                        "(the reference's DataLoader normalises every utterance on the host, two workers: a few thousand utterances/s; "
+                        "the flat path keeps up with the 44 k utterances/s of the training step); batch order then comes from "
+                        "torch.randperm(seed + epoch)")
     p.add_argument("--sync-bn", action="store_true",
                    help="data-parallel training with the native trainer: BatchNorm statistics over the global batch "
                         "(default: each rank's own statistics, as torch DistributedDataParallel)")
@@ -154,7 +159,7 @@ def main(argv=None):
     ckpt_dir = os.path.join(args.checkpoint_dir, args.run_name)
     os.makedirs(ckpt_dir, exist_ok=True)
     best_path, last_path = os.path.join(ckpt_dir, "cae_best.pt"), os.path.join(ckpt_dir, "cae_last.pt")
-    flat = world > 1                 # data-parallel input path: each rank reads only what it consumes
+    flat = world > 1 or args.flat_input     # data-parallel input path: each rank reads only what it consumes
     if flat:
         # rank 0 alone converts a features.pkl into the flat memory-mapped file; every rank maps it, fits the normaliser on its
         # share of the bonafide rows (one all-reduce) and fetches exactly the rows of its batches -- no rank un-pickles or holds
@@ -198,12 +203,12 @@ def main(argv=None):
     else:
         optimizer = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, **sched_kw)
-    if world == 1:
+    if not flat:
         train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
         val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
     best, no_improve, last_epoch = None, 0, 0
     for epoch in range(1, args.epochs + 1):
-        if world > 1:
+        if flat:
             perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(args.seed + epoch))
             idx = tr_rows[train_shard_indices(perm, args.batch_size, rank, world)]     # rows of the flat source, this rank's share
             batcher = IndexedFlatBatcher(tr_feats, None, idx, args.batch_size, device=device)

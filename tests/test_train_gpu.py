@@ -448,6 +448,18 @@ def test_train_cae_cli_end_to_end(tmp_path):
         assert (tmp_path / "cae" / f).exists()
     blob = load_checkpoint(str(tmp_path / "cae" / "cae_best.pt"))
     assert "encoder.12.weight" in blob["model_state"] and "decoder.9.bias" in blob["model_state"]
+    # the same run through the flat memory-mapped file + row-gather loader (--flat-input: the data-parallel input path on one GPU):
+    # same normaliser (fitted from the flat rows instead of the un-pickled list), validation error falling, checkpoints written
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        TC.main(["--train-features", trf, "--train-labels", trl, "--dev-features", dvf, "--dev-labels", dvl, "--epochs", "4",
+                 "--batch-size", "16", "--num-workers", "0", "--lr", "1e-3", "--checkpoint-dir", str(tmp_path),
+                 "--run-name", "cae_flat", "--flat-input"])
+    vals = [float(l.split("val_mse=")[1].split()[0]) for l in buf.getvalue().splitlines() if "val_mse=" in l]
+    assert len(vals) == 4 and vals[-1] < vals[0]
+    n0 = torch.load(str(tmp_path / "cae" / "normalizer.pt"))
+    n1 = torch.load(str(tmp_path / "cae_flat" / "normalizer.pt"))
+    assert torch.allclose(n0["mean"], n1["mean"], rtol=1e-5, atol=1e-6) and torch.allclose(n0["std"], n1["std"], rtol=1e-5, atol=1e-6)
 
 
 def test_bf16_single_launch_data_gradients_match_two_launch_path(golden):
