@@ -239,6 +239,51 @@ class IndexedFlatBatcher:
             yield f, l
 
 
+class ResidentBatcher:
+    """The training set held in HBM: the flat [N,180,321] source is uploaded ONCE (in chunks, optionally rounded to bf16 on the
+    device) and a batch is a row gather on the device (`index_select`: 59 MB in ~40 us).  An MI355X has 288 GB: 100 k utterances
+    are 23 GB in fp32, so for the reference's data sets the host never takes part in an epoch again -- the loop runs at the speed
+    of the training step (the host-fed IndexedFlatBatcher delivers ~100 k utterances/s per rank; the CNN1D step consumes 430 k).
+    Same interface and batch contents as IndexedFlatBatcher(features, labels, indices, batch_size): `epoch(indices)` returns the
+    iterable for one epoch's index order (dataloaders.train_shard_indices)."""
+
+    def __init__(self, features: torch.Tensor, labels: torch.Tensor | None, batch_size: int, device="cuda",
+                 dtype: torch.dtype | None = None, chunk_rows: int = 2048):
+        self.device, self.batch_size = torch.device(device), int(batch_size)
+        n = features.shape[0]
+        store = dtype or features.dtype
+        self.features = torch.empty((n, *features.shape[1:]), dtype=store, device=self.device)
+        for lo in range(0, n, chunk_rows):                   # bounded host staging: the source is a memory map
+            hi = min(n, lo + chunk_rows)
+            self.features[lo:hi].copy_(features[lo:hi].to(self.device, non_blocking=False))
+        self.labels = None if labels is None else labels.to(self.device)
+        self.bytes_resident = self.features.numel() * self.features.element_size()
+
+    @staticmethod
+    def fits(features: torch.Tensor, device, dtype: torch.dtype | None = None, fraction: float = 0.5) -> bool:
+        """True when the whole set takes at most `fraction` of the device's currently free memory."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            return False
+        es = torch.empty((), dtype=dtype or features.dtype).element_size()
+        free, _total = torch.cuda.mem_get_info(dev)
+        return features.numel() * es <= fraction * free
+
+    def epoch(self, indices: torch.Tensor):
+        idx = indices.to(self.device, dtype=torch.int64).reshape(-1)
+        bs, feats, labels = self.batch_size, self.features, self.labels
+
+        class _Epoch:
+            def __len__(self_inner):
+                return -(-idx.numel() // bs)
+
+            def __iter__(self_inner):
+                for lo in range(0, idx.numel(), bs):
+                    rows = idx[lo:lo + bs]
+                    yield feats.index_select(0, rows), (None if labels is None else labels.index_select(0, rows))
+        return _Epoch()
+
+
 def open_flat(features_path: str, labels_path: str | None, cache_dir: str, rank: int = 0, world: int = 1, tag: str = "set"):
     """(features tensor [N,180,321] zero-copy over a memory-mapped flat file, labels [N] float32 or None, uttids) for the
     data-parallel drivers.  `features_path` is either a flat prefix made by `python -m dfa_amd.ingest` (<prefix>.npy +

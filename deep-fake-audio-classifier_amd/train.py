@@ -21,7 +21,7 @@ from torch import nn
 
 from . import distributed as dfa_dist
 from .augmentation import FusedAugment, channel_drop, compose, gaussian_jitter, spec_augment, time_shift
-from .dataloaders import FlatBatcher, IndexedFlatBatcher, make_loader, open_flat, train_shard_indices
+from .dataloaders import FlatBatcher, IndexedFlatBatcher, ResidentBatcher, make_loader, open_flat, train_shard_indices
 from .dataset import AudioDeepfakeDataset
 from .evaluation import evaluate, evaluate_sharded
 from .model import CNN2D
@@ -155,6 +155,9 @@ def parse_args(argv=None):
     p.add_argument("--label-smoothing", type=float, default=0.0)
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     p.add_argument("--native", action="store_true", help="all-native step (fused AdamW, flat-gradient all-reduce)")
+    p.add_argument("--resident", default="auto", choices=["auto", "on", "off"],
+                   help="flat-buffer trainers: keep the whole training set in GPU memory (uploaded once; batches are device-side row "
+                        "gathers) -- auto: when it needs at most half of the free memory")
     p.add_argument("--sync-bn", action="store_true",
                    help="data-parallel training: BatchNorm statistics over the global batch (N ranks x B train like one rank x N*B); "
                         "default: each rank's own statistics, as torch DistributedDataParallel")
@@ -229,13 +232,22 @@ def main(argv=None):
 
     best_eer = best_train = best_dev = None
     no_improve, last_epoch = 0, 0
+    resident = None
     for epoch in range(1, args.epochs + 1):
         if flat_mode:
             # every rank draws the SAME permutation and takes its rows of every global batch: equal step counts and equal
             # local batch sizes on all ranks (dataloaders.train_shard_indices)
             perm = torch.randperm(feats.shape[0], generator=torch.Generator().manual_seed(args.seed + epoch))
             idx = train_shard_indices(perm, args.batch_size, rank, world)
-            batcher = IndexedFlatBatcher(feats, labels, idx, args.batch_size, device=device)
+            if resident is None and args.resident != "off" and device.type == "cuda":
+                # MI355X-first: the whole training set lives in HBM (288 GB) when it fits -- uploaded once, batches are device-side
+                # row gathers; "auto" takes it when the set needs at most half of the free memory
+                store = torch.bfloat16 if (args.precision == "bf16" and args.model == "cnn2d" and augment_fn is None) else None
+                if args.resident == "on" or ResidentBatcher.fits(feats, device, store):
+                    resident = ResidentBatcher(feats, labels, args.batch_size, device=device, dtype=store)
+                else:
+                    resident = False
+            batcher = resident.epoch(idx) if resident else IndexedFlatBatcher(feats, labels, idx, args.batch_size, device=device)
             if isinstance(trainer, FlatTrainer):
                 train_loss = train_one_epoch(model, batcher, criterion, trainer, device=device, augment_fn=augment_fn,
                                              swap_tf=args.swap_tf)

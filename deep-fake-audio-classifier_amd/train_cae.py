@@ -207,11 +207,18 @@ def main(argv=None):
         train_loader = DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
         val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
     best, no_improve, last_epoch = None, 0, 0
+    resident = None
     for epoch in range(1, args.epochs + 1):
         if flat:
             perm = torch.randperm(n_train, generator=torch.Generator().manual_seed(args.seed + epoch))
             idx = tr_rows[train_shard_indices(perm, args.batch_size, rank, world)]     # rows of the flat source, this rank's share
-            batcher = IndexedFlatBatcher(tr_feats, None, idx, args.batch_size, device=device)
+            if resident is None:
+                # the whole flat source in HBM when it needs at most half of the free memory (dataloaders.ResidentBatcher):
+                # uploaded once, batches are device-side row gathers
+                from .dataloaders import ResidentBatcher
+                resident = (ResidentBatcher(tr_feats, None, args.batch_size, device=device)
+                            if (device.type == "cuda" and ResidentBatcher.fits(tr_feats, device)) else False)
+            batcher = resident.epoch(idx) if resident else IndexedFlatBatcher(tr_feats, None, idx, args.batch_size, device=device)
             train_loss = dfa_dist.mean_scalar(train_one_epoch(model, _NormalizedBatches(batcher, nmean, nstd), criterion, optimizer, device), device)
             dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
             model._prepared = None

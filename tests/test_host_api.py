@@ -336,3 +336,27 @@ def test_host_layer_under_address_sanitizer_with_a_device():
     rc, out = _run_asan_harness()
     assert rc == 0 and "AddressSanitizer" not in out, out[-3000:]
     assert "device present, 0 failure(s)" in out
+
+
+def test_resident_batcher_yields_the_same_batches_as_the_host_fed_loader():
+    """Round 3: `dataloaders.ResidentBatcher` (the training set uploaded once, batches = device-side row gathers; SURVEY section 8(e)'s
+    loader, MI355X-first: 288 GB of HBM hold the reference's sets many times over) against `IndexedFlatBatcher` on the same index
+    order -- same rows, same labels, ragged last batch included; optional storage dtype (bf16: the rounding the first kernel would
+    apply on load).  CPU tensors here (the classes are device-agnostic); the two-rank CLI tests run it on the GPU."""
+    import torch
+    from dfa_amd.dataloaders import IndexedFlatBatcher, ResidentBatcher
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(37, 6, 5, generator=g)
+    labels = (torch.rand(37, generator=g) > 0.5).float()
+    perm = torch.randperm(37, generator=g)
+    res = ResidentBatcher(feats, labels, 8, device="cpu", chunk_rows=10)
+    got = list(res.epoch(perm))
+    want = list(IndexedFlatBatcher(feats, labels, perm, 8, device="cpu"))
+    assert len(got) == len(want) == len(res.epoch(perm)) == 5
+    for (f0, l0), (f1, l1) in zip(got, want):
+        assert torch.equal(f0, f1) and torch.equal(l0, l1)
+    assert got[-1][0].shape[0] == 5                                        # 37 = 4 x 8 + 5
+    res16 = ResidentBatcher(feats, None, 8, device="cpu", dtype=torch.bfloat16)
+    f16, l16 = next(iter(res16.epoch(perm)))
+    assert l16 is None and f16.dtype == torch.bfloat16 and torch.equal(f16, feats[perm[:8]].to(torch.bfloat16))
+    assert res16.bytes_resident == 37 * 30 * 2 and not ResidentBatcher.fits(feats, "cpu")
