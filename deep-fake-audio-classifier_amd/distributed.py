@@ -122,3 +122,41 @@ def mean_scalar(value, device=None, group=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if use_cuda else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()) / dist.get_world_size(group)
+
+
+def cpu_budget() -> int:
+    """CPUs this process may actually use: the affinity mask and the cgroup CPU quota, not the machine's count.  A GPU box reports
+    128 logical CPUs to a job that owns 16 of them; torch sizes its intra-op pool from the former, and every host-side tensor op
+    (copies, index kernels, reductions) then runs 8x oversubscribed -- measured 112 ms instead of 3 for a 59 MB batch gather
+    (tools/gpu_loader_probe.py)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts and parts[0] != "max":
+                    n = min(n, max(1, int(parts[0]) // int(parts[1])))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    period = int(fh.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def limit_cpu_threads() -> int:
+    """Cap torch's intra-op thread pool at cpu_budget() (never raises it); the command-line drivers call this first."""
+    n = cpu_budget()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()

@@ -141,6 +141,8 @@ def _add_embedding_flag(p):
 
 
 def main(argv=None):
+    from . import distributed as _dist
+    _dist.limit_cpu_threads()      # the job's CPU share, not the machine's CPU count (distributed.cpu_budget)
     args = parse_args(argv)
     device = args.device or "cuda"
     apply_sigmoid = False if args.no_apply_sigmoid else args.apply_sigmoid

@@ -177,6 +177,8 @@ def set_seed(seed: int) -> None:
 
 
 def main(argv=None):
+    from . import distributed as _dist
+    _dist.limit_cpu_threads()      # the job's CPU share, not the machine's CPU count (distributed.cpu_budget)
     args = parse_args(argv)
     set_seed(args.seed)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -147,6 +147,8 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
+    from . import distributed as _dist
+    _dist.limit_cpu_threads()      # the job's CPU share, not the machine's CPU count (distributed.cpu_budget)
     args = parse_args(argv)
     random.seed(args.seed)
     np.random.seed(args.seed)
