@@ -79,15 +79,18 @@ class _NormalizedBatches:
     """This rank's batches of an epoch from the flat source: IndexedFlatBatcher rows [b, F, T] (pinned staging, async H2D) ->
     the [b, T, F] view the model takes -> z-score on the device (src/dataset_cae.py:27-30, the dataset's transform)."""
 
-    def __init__(self, batcher, mean, std):
-        self.batcher, self.mean, self.std = batcher, mean, std
+    def __init__(self, batcher, mean, std, dtype=None):
+        self.batcher, self.mean, self.std, self.dtype = batcher, mean, std, dtype
 
     def __len__(self):
         return len(self.batcher)
 
     def __iter__(self):
         for f, _ in self.batcher:
-            yield (f.transpose(1, 2).float() - self.mean) / self.std
+            x = (f.transpose(1, 2).float() - self.mean) / self.std
+            # bf16 storage mode: the z-scored batch is held in bf16 (what the first kernel would round it to on load), so block 1 takes
+            # its matrix-core passes, which read bf16 features
+            yield x if self.dtype is None else x.to(self.dtype)
 
 
 @torch.no_grad()
@@ -221,7 +224,7 @@ def main(argv=None):
                 resident = (ResidentBatcher(tr_feats, None, args.batch_size, device=device)
                             if (device.type == "cuda" and ResidentBatcher.fits(tr_feats, device)) else False)
             batcher = resident.epoch(idx) if resident else IndexedFlatBatcher(tr_feats, None, idx, args.batch_size, device=device)
-            train_loss = dfa_dist.mean_scalar(train_one_epoch(model, _NormalizedBatches(batcher, nmean, nstd), criterion, optimizer, device), device)
+            train_loss = dfa_dist.mean_scalar(train_one_epoch(model, _NormalizedBatches(batcher, nmean, nstd, torch.bfloat16 if (args.precision == "bf16" and device.type == "cuda") else None), criterion, optimizer, device), device)
             dfa_dist.average_tensors_(dfa_dist.bn_running_stats(model))
             model._prepared = None
             val_mse = validate_reconstruction_flat(model, dv_feats, dv_rows, nmean, nstd, args.batch_size, device, rank, world)
