@@ -82,7 +82,9 @@ struct MseSrc {
   float b4, scale;
   const float* b4_dev;     // device pointer to decoder.9.bias (read once per thread)
 };
-template <typename T>
+// MODE 0: upstream gradient from drecon; 1: MSE form, x bf16; 2: MSE form, x fp32 (template: no per-element branches, so the next
+// pixel's loads -- d3 row and, in the MSE form, its four x values -- can be requested one pixel AHEAD with clamped addresses)
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void cae_dec4_bwd_kernel(const T* __restrict__ d3, const float* __restrict__ w4,
                                                            const float* __restrict__ drecon, T* __restrict__ dd3,
                                                            float* __restrict__ partial, int B, int H3, int W3, int Tt,
@@ -97,34 +99,62 @@ __global__ __launch_bounds__(256) void cae_dec4_bwd_kernel(const T* __restrict__
   float acc[129];
 #pragma unroll
   for (int k = 0; k < 129; ++k) acc[k] = 0.f;
-  const float bias4 = drecon ? 0.f : mse.b4_dev[0];
-  const size_t npix = (size_t)B * H3 * W3;
-  for (size_t p = (size_t)blockIdx.x * 256 + tid; p < npix; p += (size_t)gridDim.x * 256) {
-    const int j = (int)(p % W3);
-    const size_t bi = p / W3;
-    const int i = (int)(bi % H3), b = (int)(bi / H3);
-    float g[4];
-    float v[32], o[32];
-    ld32<T>(d3 + p * 32, v);
-    if (drecon) {
+  const float bias4 = MODE == 0 ? 0.f : mse.b4_dev[0];
+  const unsigned npix = (unsigned)((size_t)B * H3 * W3);                 // < 2^31 (launcher-checked): 32-bit pixel arithmetic
+  const unsigned stride = gridDim.x * 256u;
+  constexpr int NRAW = 32 * (int)sizeof(T) / 16;
+  uint4 rawc[NRAW], rawn[NRAW];
+  float gc[4], gn[4];                                                    // MODE 0: drecon values; MODE 1/2: raw x values (0 outside the image)
+  unsigned okc = 0, okn = 0;                                             // bit q: patch element q lies inside [T] x [F]
+  auto fetch = [&](unsigned p, uint4 (&raw)[NRAW], float (&g)[4], unsigned& ok) {
+    const unsigned pc = min(p, npix - 1);                                // clamped: a prefetch past the end re-reads the last pixel
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = 2 * i + (q >> 1), f = 2 * j + (q & 1);
-        g[q] = (t < Tt && f < F) ? drecon[((size_t)b * Tt + t) * F + f] : 0.f;
+    for (int k = 0; k < NRAW; ++k) raw[k] = reinterpret_cast<const uint4*>(d3 + (size_t)pc * 32)[k];
+    const unsigned j = pc % (unsigned)W3, bi = pc / (unsigned)W3;
+    const unsigned i = bi % (unsigned)H3, b = bi / (unsigned)H3;
+    ok = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = 2 * (int)i + (q >> 1), f = 2 * (int)j + (q & 1);
+      const bool in = t < Tt && f < F;
+      ok |= in ? (1u << q) : 0u;
+      const int tc = min(t, Tt - 1), fc = min(f, F - 1);
+      if constexpr (MODE == 0) g[q] = drecon[((size_t)b * Tt + tc) * F + fc];
+      else {
+        const int64_t off = (int64_t)b * mse.sb + (int64_t)tc * mse.st + (int64_t)fc * mse.sf;
+        if constexpr (MODE == 1) g[q] = bf16_to_float(((const bf16_t*)mse.x)[off]);
+        else g[q] = ((const float*)mse.x)[off];
+      }
+    }
+  };
+  unsigned p = blockIdx.x * 256u + tid;
+  if (p < npix) fetch(p, rawc, gc, okc);
+  for (; p < npix; p += stride) {
+    fetch(p + stride, rawn, gn, okn);                                    // next pixel: in flight under this pixel's ~400 FMAs
+    float v[32], o[32], g[4];
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int k = 0; k < NRAW; ++k) {
+        const unsigned u[4] = {rawc[k].x, rawc[k].y, rawc[k].z, rawc[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[8 * k + 2 * e] = __uint_as_float(u[e] << 16); v[8 * k + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = 2 * i + (q >> 1), f = 2 * j + (q & 1);
+      for (int k = 0; k < NRAW; ++k) {
+        v[4 * k] = __uint_as_float(rawc[k].x); v[4 * k + 1] = __uint_as_float(rawc[k].y);
+        v[4 * k + 2] = __uint_as_float(rawc[k].z); v[4 * k + 3] = __uint_as_float(rawc[k].w);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool in = (okc >> q) & 1u;
+      if constexpr (MODE == 0) g[q] = in ? gc[q] : 0.f;
+      else {
         float r = bias4;
 #pragma unroll
         for (int ci = 0; ci < 32; ++ci) r = fmaf(v[ci], wv[ci][q], r);
-        float xv = 0.f;
-        if (t < Tt && f < F) {
-          const int64_t off = (int64_t)b * mse.sb + (int64_t)t * mse.st + (int64_t)f * mse.sf;
-          xv = mse.x_bf16 ? bf16_to_float(((const bf16_t*)mse.x)[off]) : ((const float*)mse.x)[off];
-        }
-        g[q] = (t < Tt && f < F) ? mse.scale * (r - xv) : 0.f;
+        g[q] = in ? mse.scale * (r - gc[q]) : 0.f;
       }
     }
 #pragma unroll
@@ -138,8 +168,13 @@ __global__ __launch_bounds__(256) void cae_dec4_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int ci = 0; ci < 32; ++ci) ov[ci] = cvt_out<T>(o[ci]);
 #pragma unroll
-    for (int k = 0; k < (int)(32 * sizeof(T) / 16); ++k)
-      reinterpret_cast<uint4*>(dd3 + p * 32)[k] = reinterpret_cast<const uint4*>(ov)[k];
+    for (int k = 0; k < NRAW; ++k)
+      reinterpret_cast<uint4*>(dd3 + (size_t)p * 32)[k] = reinterpret_cast<const uint4*>(ov)[k];
+#pragma unroll
+    for (int k = 0; k < NRAW; ++k) rawc[k] = rawn[k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gc[q] = gn[q];
+    okc = okn;
   }
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -190,10 +225,12 @@ hipError_t launch_cae_dec4_bwd(int prec, const void* d3, const float* w4, const 
     mse.b4 = 0.f; mse.scale = 2.0f / ((float)B * (float)T * (float)F);
     mse.b4_dev = mse_args->b4_dev;
   }
-  if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(cae_dec4_bwd_kernel<bf16_t>, dim3(kDec4Blocks), dim3(256), 0, s, (const bf16_t*)d3, w4, drecon, (bf16_t*)dd3, partial, B, H3, W3, T, F, mse);
-  else
-    hipLaunchKernelGGL(cae_dec4_bwd_kernel<float>, dim3(kDec4Blocks), dim3(256), 0, s, (const float*)d3, w4, drecon, (float*)dd3, partial, B, H3, W3, T, F, mse);
+  if ((size_t)B * H3 * W3 >= ((size_t)1 << 31)) return hipErrorInvalidValue;      // 32-bit pixel indices
+  const int mode = drecon ? 0 : (mse.x_bf16 ? 1 : 2);
+#define DFA_D4B(TT, MODE) hipLaunchKernelGGL((cae_dec4_bwd_kernel<TT, MODE>), dim3(kDec4Blocks), dim3(256), 0, s, (const TT*)d3, w4, drecon, (TT*)dd3, partial, B, H3, W3, T, F, mse)
+  if (prec == DFA_PREC_BF16) { if (mode == 0) DFA_D4B(bf16_t, 0); else if (mode == 1) DFA_D4B(bf16_t, 1); else DFA_D4B(bf16_t, 2); }
+  else { if (mode == 0) DFA_D4B(float, 0); else if (mode == 1) DFA_D4B(float, 1); else DFA_D4B(float, 2); }
+#undef DFA_D4B
   return hipGetLastError();
 }
 // MSELoss(recon, x) forward + backward in one pass (src/train_cae.py:67-68, criterion at :203): every block sums its squared
