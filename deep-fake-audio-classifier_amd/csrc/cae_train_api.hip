@@ -76,6 +76,13 @@ CaeTrainPlan plan_cae_train(int B, int T, int F, int prec) {
   int ppb;
   pb = std::max(pb, (size_t)cl_stats_blocks((size_t)B * T * F, &ppb) * 256 * 2 * 4);
   pb = std::max(pb, (size_t)cae_dec4_bwd_blocks() * 132 * 4);
+  // statistics records of the convolution epilogues (cae_conv_stats): the lower half holds the records, the upper half the second
+  // reduction level of the synchronised form
+  for (int l = 1; l < 4; ++l) pb = std::max(pb, 2 * ((size_t)B * ((p.W[l] + 31) / 32) + 64) * kEC[l] * 2 * 4);
+  for (int l = 0; l < 3; ++l) {
+    const long P = (long)B * (p.Hd[l] / 2) * (l == 1 ? (p.Wd[l] - 1) / 2 : p.Wd[l] / 2);
+    pb = std::max(pb, 2 * ((size_t)cae_dec_stats_records(prec, kDCin[l], P) + 64) * kDC[l] * 2 * 4);
+  }
   p.partial = take(pb);
   p.partial_bytes = pb;
   p.total = off;
@@ -93,13 +100,14 @@ float* sums_of(char* ws, const CaeTrainPlan& pl, int layer) { return (float*)(ws
 
 // batch statistics from the block records partial[nparts][C][2]; under synchronised BatchNorm (dfa_ctx_set_bn_sync) the records are
 // reduced to one [C][2] record in the caller's buffer, summed over the ranks by the hook, and the global count is used
-int finalize_records(dfa_ctx* ctx, const float* partial, int nparts, int C, double n, const St& st, float* rm, float* rv, float momentum) {
+int finalize_records(dfa_ctx* ctx, const float* partial, int nparts, int C, double n, const St& st, float* rm, float* rv, float momentum,
+                     float* scratch = nullptr) {
   const dfa::BnSync& sy = ctx->bn_sync;
   if (!sy.fn) {
     DFA_HIP_CHECK(ctx, launch_bn_finalize(partial, nparts, C, n, st.mean, st.var, st.invstd, rm, rv, momentum, ctx->stream));
     return DFA_OK;
   }
-  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nparts, C * 2, 1.0f, sy.buf, ctx->stream, nullptr));
+  DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, nparts, C * 2, 1.0f, sy.buf, ctx->stream, scratch));
   if (sy.fn(sy.user, sy.buf, C * 2) != 0) return fail(ctx, DFA_E_HIP, "the BatchNorm synchronisation hook failed (forward statistics, %d channels)", C);
   DFA_HIP_CHECK(ctx, launch_bn_finalize(sy.buf, 1, C, n * (double)sy.world, st.mean, st.var, st.invstd, rm, rv, momentum, ctx->stream));
   return DFA_OK;
@@ -225,9 +233,12 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
     ConvArgs a{};
     a.in = ws + pl.e[l - 1]; a.wpack = m.tenc[l - 1].wpack; a.bias = m.tenc[l - 1].bias; a.out = ws + pl.z[l];
     a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l]; a.relu = 0; a.zero_page = ctx->zero_page;
+    a.stats_partial = ctx->cae_conv_stats ? partial : nullptr;   // one [COUT][2] record per (sample, 32-column strip)
     DFA_HIP_CHECK(ctx, launch_cae_train_fwd(prec, kEC[l - 1], a, (float*)(ws + pl.raw), s));
     St st = stat_of(ws, pl, l, kEC[l]);
-    int rc = finalize_stats(ctx, prec, ws + pl.z[l], (size_t)B * pl.H[l] * pl.W[l], kEC[l], st, partial, rmv(6 * l + 4), rmv(6 * l + 5), momentum);
+    const size_t npix = (size_t)B * pl.H[l] * pl.W[l];
+    int rc = ctx->cae_conv_stats ? finalize_records(ctx, partial, B * ((pl.W[l] + 31) / 32), kEC[l], (double)npix, st, rmv(6 * l + 4), rmv(6 * l + 5), momentum)
+                                 : finalize_stats(ctx, prec, ws + pl.z[l], npix, kEC[l], st, partial, rmv(6 * l + 4), rmv(6 * l + 5), momentum);
     if (rc != DFA_OK) return rc;
     DFA_HIP_CHECK(ctx, launch_bn_relu_pool(prec, 2, ws + pl.z[l], st.mean, st.invstd, p[6 * l + 2], p[6 * l + 3], ws + pl.e[l], B, pl.H[l], pl.W[l], kEC[l], s));
   }
@@ -240,10 +251,14 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
     a.wpack = m.tdec[l].wpack; a.bias = m.tdec[l].bias; a.out = ws + pl.zd[l];
     a.B = B; a.H = pl.Hd[l] / 2; a.W = (l == 1) ? (pl.Wd[l] - 1) / 2 : pl.Wd[l] / 2;
     a.COUT = kDC[l]; a.opad_w = (l == 1) ? 1 : 0; a.no_relu = 1;
+    a.stats_partial = ctx->cae_conv_stats ? partial : nullptr;   // one [COUT][2] record per workgroup (the padding column's share in record 0)
     DFA_HIP_CHECK(ctx, launch_cae_dec(prec, kDCin[l], a, s));
     if (l == 1) DFA_HIP_CHECK(ctx, launch_cae_opad_col(ws + pl.zd[1], m.tdec[1].bias, prec, B * pl.Hd[1], pl.Wd[1], 64, s, 1));
     St st = stat_of(ws, pl, 4 + l, kDC[l]);
-    int rc = finalize_stats(ctx, prec, ws + pl.zd[l], (size_t)B * pl.Hd[l] * pl.Wd[l], kDC[l], st, partial, rmv(24 + 6 * l + 4), rmv(24 + 6 * l + 5), momentum);
+    const size_t npix = (size_t)B * pl.Hd[l] * pl.Wd[l];
+    int rc = ctx->cae_conv_stats ? finalize_records(ctx, partial, cae_dec_stats_records(prec, kDCin[l], (long)B * a.H * a.W), kDC[l], (double)npix, st,
+                                                    rmv(24 + 6 * l + 4), rmv(24 + 6 * l + 5), momentum, partial + pl.partial_bytes / 8)
+                                 : finalize_stats(ctx, prec, ws + pl.zd[l], npix, kDC[l], st, partial, rmv(24 + 6 * l + 4), rmv(24 + 6 * l + 5), momentum);
     if (rc != DFA_OK) return rc;
     DFA_HIP_CHECK(ctx, launch_bn_relu_pool(prec, 1, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], ws + pl.d[l], B, pl.Hd[l], pl.Wd[l], kDC[l], s));
   }

@@ -48,6 +48,16 @@ hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStrea
 }
 
 hipError_t launch_cae_dec(int prec, int cin, const ConvTArgs& a, hipStream_t s) {
+  if (a.stats_partial) {   // train mode: pre-BatchNorm output + per-workgroup statistics records (cae_dec_stats_records of them)
+    if (prec == DFA_PREC_BF16) {
+      if (cin == 256) return launch_convt2x2<bf16_t, 256, 4, true>(a, s);
+      if (cin == 128) return launch_convt2x2<bf16_t, 128, 4, true>(a, s);
+      return launch_convt2x2<bf16_t, 64, 4, true>(a, s);
+    }
+    if (cin == 256) return launch_convt2x2<float, 256, 2, true>(a, s);
+    if (cin == 128) return launch_convt2x2<float, 128, 4, true>(a, s);
+    return launch_convt2x2<float, 64, 4, true>(a, s);
+  }
   if (prec == DFA_PREC_BF16) {
     if (cin == 256) return launch_convt2x2<bf16_t, 256, 4>(a, s);
     if (cin == 128) return launch_convt2x2<bf16_t, 128, 4>(a, s);
@@ -56,6 +66,11 @@ hipError_t launch_cae_dec(int prec, int cin, const ConvTArgs& a, hipStream_t s) 
   if (cin == 256) return launch_convt2x2<float, 256, 2>(a, s);
   if (cin == 128) return launch_convt2x2<float, 128, 4>(a, s);
   return launch_convt2x2<float, 64, 4>(a, s);
+}
+
+// number of [COUT][2] records launch_cae_dec writes to a.stats_partial for P = B H W input pixels
+int cae_dec_stats_records(int prec, int cin, long P) {
+  return (prec != DFA_PREC_BF16 && cin == 256) ? convt2x2_blocks<2>(P) : convt2x2_blocks<4>(P);
 }
 
 }  // namespace dfa

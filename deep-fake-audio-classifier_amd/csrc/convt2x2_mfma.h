@@ -20,9 +20,12 @@ struct ConvTArgs {
   void* out;           // [B][2H][2W+opad_w][COUT] T
   int B, H, W, COUT, opad_w;
   int no_relu;         // 1: store bias + sum without the ReLU (train mode: BatchNorm runs as its own pass)
+  // STATS form (train mode): per-workgroup [COUT][2] records of the sum / sum of squares of the values stored (fp32, before the
+  // rounding for storage); workgroup 0 adds the opad_w column (bias only, written by cae_opad_col_kernel): B * 2H pixels of bias
+  float* stats_partial;
 };
 
-template <typename T, int CIN, int MSUB>
+template <typename T, int CIN, int MSUB, bool STATS = false>
 __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
   constexpr int ES = sizeof(T), KG = 32 / ES, NKG = CIN / KG, PB = CIN * ES, CPP = PB / 16;
   constexpr int MTILE = 32 * MSUB;
@@ -60,6 +63,10 @@ __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
 
   const int nslices = 4 * COUT / 32;
   T* out = (T*)a.out;
+  // STATS: slices wave, wave + 4, ... of one wave all carry the SAME 32 output channels (nslices = 4 COUT / 32 with COUT / 32 in
+  // {1, 2, 4} groups: slice s <-> group s % (COUT / 32), and 4 is a multiple of that) at different patch positions: one running
+  // pair per lane
+  float st1 = 0.f, st2 = 0.f;
   for (int s = wave; s < nslices; s += 4) {
     uint4 wb[NKG];
     const uint4* wp = a.wpack + (size_t)s * NKG * 64 + lane;
@@ -86,17 +93,49 @@ __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ob = obase[ms * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
-        if (ob >= 0) out[(size_t)(ob + oshift) * COUT + co] = cvt_out<T>(a.no_relu ? acc[i] + bv : fmaxf(acc[i] + bv, 0.f));
+        if (ob >= 0) {
+          const float v = acc[i] + bv;
+          out[(size_t)(ob + oshift) * COUT + co] = cvt_out<T>((STATS || a.no_relu) ? v : fmaxf(v, 0.f));
+          if (STATS) { st1 += v; st2 = fmaf(v, v, st2); }
+        }
       }
+    }
+  }
+  if (STATS) {
+    // lane (r, h): channel group g = wave % (COUT / 32), channel 32 g + r, pixels 4 h + ...: fold the halves, park one pair per
+    // (wave, r), then add the waves of a group in wave order (a fixed order: the records are reproducible)
+    st1 += __shfl_xor(st1, 32, 64);
+    st2 += __shfl_xor(st2, 32, 64);
+    __syncthreads();                                   // every wave is done with the input tile: its first bytes become the scratch
+    float* red = (float*)smem;
+    if (h == 0) { red[(wave * 32 + r) * 2] = st1; red[(wave * 32 + r) * 2 + 1] = st2; }
+    __syncthreads();
+    if (tid < COUT) {
+      const int ng = COUT / 32, g = tid >> 5, rr = tid & 31;
+      float s1 = 0.f, s2 = 0.f;
+      for (int w = g; w < 4; w += ng) { s1 += red[(w * 32 + rr) * 2]; s2 += red[(w * 32 + rr) * 2 + 1]; }
+      if (a.opad_w && blockIdx.x == 0) {
+        const float bvv = a.bias[tid], np = (float)(a.B * Ho);
+        s1 = fmaf(np, bvv, s1);
+        s2 = fmaf(np * bvv, bvv, s2);
+      }
+      float* dst = a.stats_partial + ((size_t)blockIdx.x * COUT + tid) * 2;
+      dst[0] = s1;
+      dst[1] = s2;
     }
   }
 }
 
-template <typename T, int CIN, int MSUB>
+// records of the STATS form
+template <int MSUB>
+inline int convt2x2_blocks(long P) { return (int)((P + 32 * MSUB - 1) / (32 * MSUB)); }
+
+template <typename T, int CIN, int MSUB, bool STATS = false>
 hipError_t launch_convt2x2(const ConvTArgs& a, hipStream_t stream) {
   constexpr int PB = CIN * (int)sizeof(T), MTILE = 32 * MSUB;
   constexpr int LDS = MTILE * PB + MTILE * 4;
-  auto kern = convt2x2_mfma_kernel<T, CIN, MSUB>;
+  if (STATS && (!a.stats_partial || !a.no_relu || a.COUT > 128 || (a.COUT != 32 && a.COUT != 64 && a.COUT != 128))) return hipErrorInvalidValue;
+  auto kern = convt2x2_mfma_kernel<T, CIN, MSUB, STATS>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -130,6 +130,7 @@ struct dfa_ctx {
   int cae_enc1_mfma = 1;       // auto-encoder eval forward, bf16 mode: block 1 on the matrix cores (cae_enc1_mfma.hip); 0 = the vector-ALU kernel
   int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
   int cae_dgrad_mfma = 1;      // auto-encoder training, bf16 mode: ConvTranspose2d data gradients on the bf16 matrix cores writing bf16
+  int cae_conv_stats = 1;      // auto-encoder training: encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (0 = separate pass over z)
                                // (convt_dgrad_bf16.hip); 0 = the fp32-MFMA GEMM + cast pass of round 2
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_train_x3 = 1;      // CNN1D training convolutions (3 forward, 2 data gradients) on the matrix-core layer kernel (conv1d_x3_kernel) where
@@ -389,5 +390,6 @@ hipError_t launch_cae_enc2(int prec, const ConvArgs& a, hipStream_t s, int pipe 
 hipError_t launch_cae_enc3(int prec, const ConvArgs& a, hipStream_t s, int pipe = 1, int dma = 0);
 hipError_t launch_cae_enc4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s, int dma = 0);
 hipError_t launch_cae_dec(int prec, int cin, const ConvTArgs& a, hipStream_t s);
+int cae_dec_stats_records(int prec, int cin, long P);
 
 }  // namespace dfa

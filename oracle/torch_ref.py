@@ -239,15 +239,17 @@ def state_after_adamw_step(sd, grads, stats, lr=1e-3, weight_decay=0.01, momentu
     return out
 
 
-def cae_train_step_emulated(sd, x, emulate="bf16"):
+def cae_train_step_emulated(sd, x, emulate="bf16", stats="epilogue"):
     """One ConvAutoencoder training forward/backward (src/train_cae.py:58-82 over src/model_cae.py:32-125 in train mode, loss =
     MSELoss(recon, x)) restated with the ROUNDING POINTS of the product's bf16 training mode (csrc/cae_train_api.hip):
       encoder block 1   fp32 convolution from the bf16 features, z1 never stored (statistics of the unrounded z1); its pooled
                         output e1 and the gradient de1 that arrives for it are stored in bf16;
-      encoder 2-4       MFMA convolutions with bf16 weights on bf16 inputs; the pre-BatchNorm output z is STORED in bf16 and
-                        the batch statistics are taken from the stored tensor (cl_stats pass), as is the normalisation; the
-                        BatchNorm backward writes dz in bf16; pooled outputs e and their gradients de in bf16;
-      decoder 1-3       ConvTranspose2d(k2, s2) with bf16 weights, zd / dzd / d / dd stored in bf16, statistics of the stored zd;
+      encoder 2-4       MFMA convolutions with bf16 weights on bf16 inputs; the pre-BatchNorm output z is STORED in bf16; the
+                        batch statistics are the convolution epilogue's fp32 sums of the UNROUNDED outputs (context option
+                        cae_conv_stats = 1, the default; stats="stored" restates the separate pass over the stored tensor of
+                        option 0 and of round 2), the normalisation reads the stored tensor; the BatchNorm backward writes dz in
+                        bf16; pooled outputs e and their gradients de in bf16;
+      decoder 1-3       ConvTranspose2d(k2, s2) with bf16 weights, zd / dzd / d / dd stored in bf16, statistics as in the encoder;
       decoder 4         fp32 from the bf16 d3.
     (The product's ConvTranspose2d DATA gradient multiplies by the unrounded fp32 weights; here the rounded ones are used in both
     directions -- a 2^-9 relative difference per weight, below the bf16 storage of the result.)  Everything else is float64
@@ -257,6 +259,8 @@ def cae_train_step_emulated(sd, x, emulate="bf16"):
     on = emulate == "bf16"
     if emulate not in (None, "bf16"):
         raise ValueError(emulate)
+    if stats not in ("epilogue", "stored"):
+        raise ValueError(stats)
     P = {k: _t(sd, k).to(f64).clone().requires_grad_(True) for k in sd
          if k.endswith(("weight", "bias")) and not k.endswith(("running_mean", "running_var"))}
     store = _StoreBF16.apply if on else (lambda t: t)
@@ -267,24 +271,26 @@ def cae_train_step_emulated(sd, x, emulate="bf16"):
         w = P[name]
         return w + (rnd(w) - w).detach() if on else w
 
-    def bn(z, pfx):
-        mean = z.mean(dim=(0, 2, 3), keepdim=True)
-        var = z.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    def bn(z, pfx, zu=None):
+        # zu: the unrounded values the statistics are summed from (their gradient still arrives through the stored tensor's dz)
+        zs = z if (zu is None or stats == "stored") else z + (zu - z).detach()
+        mean = zs.mean(dim=(0, 2, 3), keepdim=True)
+        var = zs.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
         return (z - mean) / torch.sqrt(var + 1e-5) * P[pfx + ".weight"][None, :, None, None] + P[pfx + ".bias"][None, :, None, None]
 
-    def stored(z):              # pre-BN output kept in bf16 (forward value rounded, statistics of the rounded value), dz in bf16
+    def stored(z):              # pre-BN output kept in bf16 (forward value rounded), dz in bf16
         return rnd(rgrad(z))
 
     xb = (x.to(torch.bfloat16) if on else x).to(f64)
     h = xb.unsqueeze(1)
     h = store(F.avg_pool2d(F.relu(bn(F.conv2d(h, P["encoder.0.weight"], P["encoder.0.bias"], padding=1), "encoder.1")), 2))
     for c, b in ((4, 5), (8, 9), (12, 13)):
-        z = stored(F.conv2d(h, wq(f"encoder.{c}.weight"), P[f"encoder.{c}.bias"], padding=1))
-        h = store(F.avg_pool2d(F.relu(bn(z, f"encoder.{b}")), 2))
+        zu = F.conv2d(h, wq(f"encoder.{c}.weight"), P[f"encoder.{c}.bias"], padding=1)
+        h = store(F.avg_pool2d(F.relu(bn(stored(zu), f"encoder.{b}", zu)), 2))
     d = h
     for c, b, opad in ((0, 1, (0, 0)), (3, 4, (0, 1)), (6, 7, (0, 0))):
-        z = stored(F.conv_transpose2d(d, wq(f"decoder.{c}.weight"), P[f"decoder.{c}.bias"], stride=2, output_padding=opad))
-        d = store(F.relu(bn(z, f"decoder.{b}")))
+        zu = F.conv_transpose2d(d, wq(f"decoder.{c}.weight"), P[f"decoder.{c}.bias"], stride=2, output_padding=opad)
+        d = store(F.relu(bn(stored(zu), f"decoder.{b}", zu)))
     r = F.conv_transpose2d(d, P["decoder.9.weight"], P["decoder.9.bias"], stride=2)
     T, Tr = x.size(1), r.size(2)
     if Tr < T:

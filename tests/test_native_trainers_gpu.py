@@ -156,7 +156,7 @@ def test_flat_trainer_bridge_writes_gradients_straight_into_the_flat_buffer(gold
     assert first.grad is not None and torch.isfinite(first.grad).all()
 
 
-@pytest.mark.parametrize("option", ["cae_dgrad_mfma", "conv1_mfma", "dgrad_m16"])
+@pytest.mark.parametrize("option", ["cae_dgrad_mfma", "conv1_mfma", "dgrad_m16", "cae_conv_stats"])
 @pytest.mark.parametrize("B,T,F", [(3, 96, 180), (2, 321, 180), (5, 48, 36)])
 def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, option):
     """Round 3, auto-encoder training step in bf16 mode (autograd of src/model_cae.py:40-79 inside loss.backward(),
@@ -169,6 +169,9 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
       differs by isolated bf16 ulps of the block-1 output, so the loss agrees to 2e-4.
     * dgrad_m16 -- the encoder's 64 -> 32 and 128 -> 64 data gradients on the 16x16x32 kernels of conv_split.hip (one launch each, as
       the CNN2D's) instead of the 32x32x16 forms (the second chained through fp32 partial sums): same products, other summation order.
+    * cae_conv_stats -- encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (fp32 sums of the outputs before
+      they are rounded for storage, as the CNN2D's blocks 2 / 3) instead of a separate pass over the stored bf16 output: mean and
+      variance move by the (unbiased) storage rounding averaged over the batch, the loss agrees to 5e-4.
     Every gradient within 3 % relative L2 (the bound the emulated-oracle test gives decoder gradients; seven BatchNorm + ReLU
     layers amplify any re-rounding), convolution biases in front of a BatchNorm (gradient zero up to rounding) on their weight's
     scale, and the decoder's last block -- upstream of every changed kernel -- bit-identical for the data-gradient option."""
@@ -177,7 +180,7 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
     g = torch.Generator().manual_seed(B * 7 + T)
     x = torch.randn(B, T, F, generator=g).to("cuda", torch.bfloat16)
     ctx = _lib.Context.get(x.device)
-    res = {}
+    res, stats = {}, {}
     try:
         for arm in (0, 1):
             ctx.set_option(option, arm)
@@ -187,12 +190,24 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
             loss = torch.nn.functional.mse_loss(recon, x.float())
             loss.backward()
             res[arm] = (float(loss), {n: p.grad.clone() for n, p in m.named_parameters()})
+            stats[arm] = {n: b.clone() for n, b in m.named_buffers() if "running_" in n}
     finally:
         ctx.set_option(option, 1)
+    if option == "cae_conv_stats":
+        # the statistics themselves (through the running buffers one step updates): the epilogue's sums are those of the separate pass up to
+        # the storage rounding of z (2^-9 per element, unbiased) -- a miscounted strip edge or row would show here at the 1e-3 .. 1e-2 level (0.1 / W of the variance)
+        for n, b0 in stats[0].items():
+            if n.startswith("encoder.1."):     # block 1: untouched
+                assert torch.equal(stats[1][n], b0), n
+            # (the decoder's layers also see the encoder's re-rounded output)
+            assert float((stats[1][n] - b0).abs().max()) <= (1e-4 if n.startswith("encoder.") else 3e-4) * max(float(b0.abs().max()), 1.0), n
+    forward_changes = option in ("conv1_mfma", "cae_conv_stats")
     if option in ("cae_dgrad_mfma", "dgrad_m16"):
         assert res[0][0] == res[1][0]
     else:
-        assert abs(res[0][0] - res[1][0]) <= 2e-4 * abs(res[0][0])
+        # (statistics option: a layer with n pixels per channel moves its mean by ~2^-9 / sqrt(n) of a standard deviation -- n = 120 in
+        # the last encoder block of the [5,48,36] batch: 2.2e-4 measured there, 7e-5 on [256,321,180])
+        assert abs(res[0][0] - res[1][0]) <= (5e-4 if option == "cae_conv_stats" else 2e-4) * abs(res[0][0])
     worst = 0.0
     for n, g0 in res[0][1].items():
         g1 = res[1][1][n]
@@ -204,10 +219,10 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
             # a convolution bias in front of a BatchNorm: its gradient is zero up to rounding -- compare on the weight gradient's scale
             assert float((g1 - g0).abs().max()) <= 1e-2 * float(res[0][1][n[:-5] + ".weight"].abs().max()), n   # (bf16 storage noise of dz)
             continue
-        # end to end the block-1 option also changes the forward (isolated bf16 ulps of the block-1 output): the encoder's gradients
+        # end to end the block-1 and statistics options also change the forward (isolated bf16 ulps of a block's output): the encoder's gradients
         # then differ like any two valid bf16 implementations do -- the regime of the emulated-oracle test's 10 % bound (measured 7 % at [2,321,180], 10 % at the tiny [3,96,180]); the backward
         # pass itself is held to 1 % below, on one forward state
-        assert rel <= (2e-1 if option == "conv1_mfma" else 3e-2), (n, rel)
+        assert rel <= (2e-1 if forward_changes else 3e-2), (n, rel)
         worst = max(worst, rel)
     print(f"cae {option} 1 vs 0 [{B},{T},{F}]: worst relative L2 over the gradients {worst:.2e}")
     if option != "conv1_mfma":
