@@ -76,6 +76,11 @@ CaeTrainPlan plan_cae_train(int B, int T, int F, int prec) {
   int ppb;
   pb = std::max(pb, (size_t)cl_stats_blocks((size_t)B * T * F, &ppb) * 256 * 2 * 4);
   pb = std::max(pb, (size_t)cae_dec4_bwd_blocks() * 132 * 4);
+  // channel-sum records of the decoder's folded BatchNorm-backward apply pass (cae_bwd_fold): one [C] record per 16 * (256 / (C / 8)) pixels
+  for (int l = 0; l < 3; ++l) {
+    const size_t npix = (size_t)B * p.Hd[l] * p.Wd[l], ppb2 = 16 * (256 / (kDC[l] / 8));
+    pb = std::max(pb, 2 * ((npix + ppb2 - 1) / ppb2 + 64) * kDC[l] * 4);
+  }
   // statistics records of the convolution epilogues (cae_conv_stats): the lower half holds the records, the upper half the second
   // reduction level of the synchronised form
   for (int l = 1; l < 4; ++l) pb = std::max(pb, 2 * ((size_t)B * ((p.W[l] + 31) / 32) + 64) * kEC[l] * 2 * 4);
@@ -311,6 +316,15 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     const long P = (long)B * Hin * Win;
     St st = stat_of(ws, pl, 4 + l, Cout);
     float* sm = sums_of(ws, pl, 4 + l);
+    if (ctx->cae_bwd_fold) {
+      // one apply pass writes dz patch-major (what the two gradient GEMMs read) and leaves the records of its channel sums = the
+      // ConvTranspose2d bias gradient (over ALL output pixels, the output_padding column included): dzd itself is never stored
+      dfa::BnBwdFold fold{ws + pl.zp, Win, partial, 0};
+      DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_DIRECT, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], nullptr, ws + pl.dd[l], partial, sm,
+                                       nullptr, B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s, scratch2, sync, &fold));
+      hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[16 + 4 * l + 2], grads[16 + 4 * l + 3], Cout);
+      DFA_HIP_CHECK(ctx, launch_reduce_partials(partial, fold.nrec, Cout, 1.0f, grads[16 + 4 * l + 1], s, scratch2));
+    } else {
     DFA_HIP_CHECK(ctx, launch_bn_bwd(prec, SRC_DIRECT, ws + pl.zd[l], st.mean, st.invstd, q[2], q[3], nullptr, ws + pl.dd[l], partial, sm,
                                      ws + pl.dzd[l], B, pl.Hd[l], pl.Wd[l], Cout, nodrop, s, scratch2, sync));
     hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, sm, grads[16 + 4 * l + 2], grads[16 + 4 * l + 3], Cout);
@@ -323,6 +337,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
       hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(256), 0, s, scratch_c, scratch_c + 512, grads[16 + 4 * l + 1], Cout);
     }
     DFA_HIP_CHECK(ctx, launch_pixel_unshuffle(prec, ws + pl.dzd[l], ws + pl.zp, B, Hin, Win, pl.Wd[l], Cout, s));
+    }
     float* wq = (float*)(ws + pl.wq);
     DFA_HIP_CHECK(ctx, launch_convt_w_to_q(q[0], wq, Cin, Cout, s));
     // data gradient: dX[P x Cin] = Zp[P x 4Cout] . Wq^T

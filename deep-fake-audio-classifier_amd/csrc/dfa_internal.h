@@ -131,6 +131,7 @@ struct dfa_ctx {
   int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
   int cae_dgrad_mfma = 1;      // auto-encoder training, bf16 mode: ConvTranspose2d data gradients on the bf16 matrix cores writing bf16
   int cae_conv_stats = 1;      // auto-encoder training: encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (0 = separate pass over z)
+  int cae_bwd_fold = 1;        // auto-encoder training: the decoder's BatchNorm-backward apply pass writes dz patch-major and sums the ConvTranspose2d bias gradient (0 = three passes)
                                // (convt_dgrad_bf16.hip); 0 = the fp32-MFMA GEMM + cast pass of round 2
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_train_x3 = 1;      // CNN1D training convolutions (3 forward, 2 data gradients) on the matrix-core layer kernel (conv1d_x3_kernel) where
@@ -312,9 +313,13 @@ hipError_t launch_bn_bwd_meant_saved(int prec, const void* z, const float* mean,
 hipError_t launch_linear_bwd(const float* dlogits, const float* w, const float* emb, float* demb, float* dw, float* db,
                              int B, int K, hipStream_t s, int tc = 0, int tw = 0);
 int bn_bwd_blocks(int B, int H, int W, int* pix_per_block);
+// SRC_DIRECT apply pass that writes dz patch-major (the pixel-unshuffled operand of a ConvTranspose2d(k2, s2) layer's gradient GEMMs,
+// Wh input columns) and leaves [nrec][C] records of its channel sums in bias_partial (train_elem.hip bn_bwd_apply_unshuffle_kernel)
+struct BnBwdFold { void* zp; int Wh; float* bias_partial; int nrec; };
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
-                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch = nullptr, const BnSync* sync = nullptr);
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch = nullptr, const BnSync* sync = nullptr,
+                         BnBwdFold* fold = nullptr);
 hipError_t launch_bce_smooth(const float* logits, const float* labels, float eps, int B, float* loss, float* dlogits,
                              hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,

@@ -530,6 +530,65 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- apply pass of a ConvTranspose2d(k2, s2) + BatchNorm layer (auto-encoder decoder, SRC_DIRECT) that also does what its two
+// consumers used to do in passes of their own: dz is written straight in the PATCH-MAJOR order the layer's gradient GEMMs read
+// (zp[(b, t/2, f/2)][q = 2 (t&1) + (f&1)][C], `pixel_unshuffle_kernel`; a trailing output_padding column has no input pixel and is
+// not stored) and its per-channel sums -- the convolution's bias gradient, every output pixel included -- leave as one [C] record
+// per workgroup (summed as stored: after the rounding to T).  Same per-element formulas as bn_bwd_apply_kernel<T, SRC_DIRECT>.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_unshuffle_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ sums,
+                                                                     const T* __restrict__ da, T* __restrict__ zp,
+                                                                     float* __restrict__ bias_partial, int B, int H, int W, int C,
+                                                                     int Wh, float inv_n, int pix_per_block) {
+  extern __shared__ float red[];  // [PL][C]
+  const int CG = C >> 3, PL = 256 / CG;
+  const int tid = threadIdx.x, cg = tid % CG, pl = tid / CG;
+  const size_t npix = (size_t)B * H * W;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+  float mu[8], is[8], gm[8], bt[8], k0[8], k1[8], k2[8], bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c]; is[j] = invstd[c]; gm[j] = gamma[c]; bt[j] = beta[c];
+    k0[j] = gm[j] * is[j];
+    k1[j] = sums[2 * c] * inv_n;
+    k2[j] = sums[2 * c + 1] * inv_n;
+    bs[j] = 0.f;
+  }
+  const unsigned Hh = (unsigned)H >> 1;
+#pragma unroll 4
+  for (unsigned p = (unsigned)p0 + pl; p < (unsigned)p1; p += PL) {
+    const unsigned f = p % (unsigned)W, bt_ = p / (unsigned)W;
+    const unsigned t = bt_ % (unsigned)H, b = bt_ / (unsigned)H;
+    float v[8], g[8], o[8];
+    ld8<T>(z + (size_t)p * C + cg * 8, v);
+    ld8<T>(da + (size_t)p * C + cg * 8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mu[j]) * is[j];
+      const float dy = (fmaf(gm[j], xh, bt[j]) > 0.f) ? g[j] : 0.f;
+      o[j] = k0[j] * (dy - k1[j] - xh * k2[j]);
+      bs[j] += (sizeof(T) == 2) ? bf16_to_float(float_to_bf16(o[j])) : o[j];
+    }
+    if ((f >> 1) < (unsigned)Wh) {
+      const size_t dst = ((((size_t)b * Hh + (t >> 1)) * Wh + (f >> 1)) * 4 + ((t & 1u) << 1) + (f & 1u)) * C + cg * 8;
+      st8<T>(zp + dst, o);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[pl * C + cg * 8 + j] = bs[j];
+  __syncthreads();
+  for (int e = tid; e < C; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * C + e];
+    bias_partial[(size_t)blockIdx.x * C + e] = s;
+  }
+}
+
 // ---- SRC_POOL reduction and apply pass on ROW PAIRS (H even): a thread takes a pooled pixel (to, f) x 8 channels -- ONE upstream load and ONE dropout
 // draw serve the two rows 2*to, 2*to+1 of z that were averaged into it; several pooled pixels in flight per thread.  Same
 // per-element formulas as the generic kernel (which ran one dependent 16-byte load at a time: 3.0 TB/s).
@@ -871,9 +930,11 @@ int bn_bwd_blocks(int B, int H, int W, int* pix_per_block) {
 // two-level reduction of the block records (nullptr: one level)
 hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* demb, const void* da, float* partial, float* sums, void* dz,
-                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch, const BnSync* sync) {
+                         int B, int H, int W, int C, const DropCfg& dc, hipStream_t s, float* scratch, const BnSync* sync,
+                         BnBwdFold* fold) {
   int ppb;
   int nblk = bn_bwd_blocks(B, H, W, &ppb);
+  if (fold && (src != SRC_DIRECT || (H & 1) || 2 * fold->Wh > W || !fold->zp || !fold->bias_partial)) return hipErrorInvalidValue;
   if ((size_t)B * H * W >= ((size_t)1 << 31)) return hipErrorInvalidValue;     // 32-bit pixel indices in the generic kernels
   if (src == SRC_DIRECT || src == SRC_POOL22) {   // the auto-encoder's layers (55-900 blocks of 4096 pixels did not fill the chip)
     ppb = 1024;
@@ -915,7 +976,11 @@ hipError_t launch_bn_bwd(int prec, int src, const void* z, const float* mean, co
     if (e != hipSuccess) return e;                                                                                     \
     e = bn_sync_sums(sync, sums, C * 2, s, &sums_a, &isc);                                                             \
     if (e != hipSuccess) return e;                                                                                     \
-    if (dz)                                                                                                            \
+    if (fold) {                                                                                                        \
+      fold->nrec = (int)g2.x;                                                                                          \
+      hipLaunchKernelGGL((bn_bwd_apply_unshuffle_kernel<TT>), g2, dim3(256), lds / 2, s, (const TT*)z, mean, invstd, gamma, beta, \
+                         sums_a, (const TT*)da, (TT*)fold->zp, fold->bias_partial, B, H, W, C, fold->Wh, inv_n * isc, ppb2);  \
+    } else if (dz)                                                                                                     \
       hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, SRC>), g2, dim3(256), 0, s, (const TT*)z, mean, invstd, gamma, beta, sums_a, \
                          demb, (const TT*)da, (TT*)dz, B, H, W, C, dc, inv_n * isc, ppb2);                                  \
   } while (0)

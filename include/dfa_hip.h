@@ -96,9 +96,12 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   0 = through registers (bit-identical)
  *   "cae_dgrad_mfma" 1 (default) = auto-encoder training step in bf16 mode: the three ConvTranspose2d data gradients on the bf16
  *                   matrix cores, bf16 result written in place (convt_dgrad_bf16.hip); 0 = fp32-MFMA GEMM + cast pass
- *   "cae_conv_stats" 1 (default) = auto-encoder training step: encoder blocks 2-4 take their BatchNorm batch statistics in the
+ *   "cae_conv_stats" 1 (default) = auto-encoder training step: encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm batch statistics in the
  *                   convolution's epilogue (fp32 sums of the outputs before they are rounded for storage, as the CNN2D's blocks 2 / 3);
  *                   0 = a separate statistics pass over the stored output
+ *   "cae_bwd_fold"  1 (default) = auto-encoder training step: the BatchNorm-backward apply pass of decoder blocks 1-3 writes dz in the
+ *                   patch-major order the ConvTranspose2d gradient GEMMs read and sums the bias gradient on the way; 0 = apply pass,
+ *                   channel-sum pass and pixel-unshuffle pass (same values)
  *   "cae_dec_fused" 1 (default) = auto-encoder eval forward in bf16 mode: the four decoder blocks, the zero time padding and the
  *                   per-sample squared error run as ONE kernel with the intermediates in LDS / registers; 0 = four launches
  *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel for T <= 384 (all three Conv1d layers on the matrix cores with the

@@ -156,7 +156,7 @@ def test_flat_trainer_bridge_writes_gradients_straight_into_the_flat_buffer(gold
     assert first.grad is not None and torch.isfinite(first.grad).all()
 
 
-@pytest.mark.parametrize("option", ["cae_dgrad_mfma", "conv1_mfma", "dgrad_m16", "cae_conv_stats"])
+@pytest.mark.parametrize("option", ["cae_dgrad_mfma", "conv1_mfma", "dgrad_m16", "cae_conv_stats", "cae_bwd_fold"])
 @pytest.mark.parametrize("B,T,F", [(3, 96, 180), (2, 321, 180), (5, 48, 36)])
 def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, option):
     """Round 3, auto-encoder training step in bf16 mode (autograd of src/model_cae.py:40-79 inside loss.backward(),
@@ -172,6 +172,9 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
     * cae_conv_stats -- encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (fp32 sums of the outputs before
       they are rounded for storage, as the CNN2D's blocks 2 / 3) instead of a separate pass over the stored bf16 output: mean and
       variance move by the (unbiased) storage rounding averaged over the batch, the loss agrees to 5e-4.
+    * cae_bwd_fold -- the decoder's BatchNorm-backward apply pass writes dz patch-major (no pixel-unshuffle pass) and sums the
+      ConvTranspose2d bias gradient on the way (no channel-sum pass): the same dz values, so every gradient is bit-identical except
+      those bias gradients (zero up to rounding; another summation order).
     Every gradient within 3 % relative L2 (the bound the emulated-oracle test gives decoder gradients; seven BatchNorm + ReLU
     layers amplify any re-rounding), convolution biases in front of a BatchNorm (gradient zero up to rounding) on their weight's
     scale, and the decoder's last block -- upstream of every changed kernel -- bit-identical for the data-gradient option."""
@@ -202,7 +205,7 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
             # (the decoder's layers also see the encoder's re-rounded output)
             assert float((stats[1][n] - b0).abs().max()) <= (1e-4 if n.startswith("encoder.") else 3e-4) * max(float(b0.abs().max()), 1.0), n
     forward_changes = option in ("conv1_mfma", "cae_conv_stats")
-    if option in ("cae_dgrad_mfma", "dgrad_m16"):
+    if option in ("cae_dgrad_mfma", "dgrad_m16", "cae_bwd_fold"):
         assert res[0][0] == res[1][0]
     else:
         # (statistics option: a layer with n pixels per channel moves its mean by ~2^-9 / sqrt(n) of a standard deviation -- n = 120 in
@@ -219,6 +222,8 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
             # a convolution bias in front of a BatchNorm: its gradient is zero up to rounding -- compare on the weight gradient's scale
             assert float((g1 - g0).abs().max()) <= 1e-2 * float(res[0][1][n[:-5] + ".weight"].abs().max()), n   # (bf16 storage noise of dz)
             continue
+        if option == "cae_bwd_fold":
+            assert torch.equal(g0, g1), n
         # end to end the block-1 and statistics options also change the forward (isolated bf16 ulps of a block's output): the encoder's gradients
         # then differ like any two valid bf16 implementations do -- the regime of the emulated-oracle test's 10 % bound (measured 7 % at [2,321,180], 10 % at the tiny [3,96,180]); the backward
         # pass itself is held to 1 % below, on one forward state
