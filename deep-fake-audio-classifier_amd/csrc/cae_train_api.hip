@@ -238,11 +238,12 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
     ConvArgs a{};
     a.in = ws + pl.e[l - 1]; a.wpack = m.tenc[l - 1].wpack; a.bias = m.tenc[l - 1].bias; a.out = ws + pl.z[l];
     a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l]; a.relu = 0; a.zero_page = ctx->zero_page;
-    a.stats_partial = ctx->cae_conv_stats ? partial : nullptr;   // one [COUT][2] record per (sample, 32-column strip)
+    const bool epi_stats = ctx->cae_conv_stats && l < 3;         // (block 4: conv3x3_inst_cae_train.hip)
+    a.stats_partial = epi_stats ? partial : nullptr;             // one [COUT][2] record per (sample, 32-column strip)
     DFA_HIP_CHECK(ctx, launch_cae_train_fwd(prec, kEC[l - 1], a, (float*)(ws + pl.raw), s));
     St st = stat_of(ws, pl, l, kEC[l]);
     const size_t npix = (size_t)B * pl.H[l] * pl.W[l];
-    int rc = ctx->cae_conv_stats ? finalize_records(ctx, partial, B * ((pl.W[l] + 31) / 32), kEC[l], (double)npix, st, rmv(6 * l + 4), rmv(6 * l + 5), momentum)
+    int rc = epi_stats ? finalize_records(ctx, partial, B * ((pl.W[l] + 31) / 32), kEC[l], (double)npix, st, rmv(6 * l + 4), rmv(6 * l + 5), momentum)
                                  : finalize_stats(ctx, prec, ws + pl.z[l], npix, kEC[l], st, partial, rmv(6 * l + 4), rmv(6 * l + 5), momentum);
     if (rc != DFA_OK) return rc;
     DFA_HIP_CHECK(ctx, launch_bn_relu_pool(prec, 2, ws + pl.z[l], st.mean, st.invstd, p[6 * l + 2], p[6 * l + 3], ws + pl.e[l], B, pl.H[l], pl.W[l], kEC[l], s));

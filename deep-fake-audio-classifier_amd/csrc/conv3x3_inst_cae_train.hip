@@ -5,37 +5,43 @@
 
 namespace dfa {
 
-// forward, pre-BN output z; with a.stats_partial set, the BatchNorm statistics ride on the epilogue as in the CNN2D's blocks 2 / 3
-// (records [B * strips][COUT][2], conv3x3_mfma.h) -- no separate pass over z
+// forward, pre-BN output z.  With a.stats_partial set (encoder blocks 2 and 3), the BatchNorm statistics ride on the epilogue as in
+// the CNN2D's blocks 2 / 3 (records [B * strips][COUT][2], conv3x3_mfma.h; block 2 IS the CNN2D's block-2 kernel) -- no separate
+// pass over z.  Block 4 (one 22-column strip per sample at F = 180: little work per workgroup) keeps the separate pass: the
+// epilogue's fixed cost (+49 us) was twice the pass over its 118 MB output.
+hipError_t launch_train_fwd2(int prec, const ConvArgs& a, hipStream_t s);
+hipError_t launch_train_fwd3(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
   const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
   if (cin == 32) {
-    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 1, false, false, true>(a, s);
-    return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_PLAIN, 1, false, false, true>(a, s);
+    if (a.stats_partial) return launch_train_fwd2(prec, a, s);
+    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 32, 2, 2, 2, 1, EPI_PLAIN, 1>(a, s);
+    return launch_conv3x3<float, 32, 2, 2, 2, 1, EPI_PLAIN, 1>(a, s);
   }
   if (cin == 64) {
-    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1, false, false, true>(a, s);
-    return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, false, true, true>(a, s);
+    if (a.stats_partial) return launch_train_fwd3(prec, a, s);
+    if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1>(a, s);
+    return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, false, true>(a, s);
   }
   // cin == 128: two 64-channel halves; a.wpack holds the two images back to back
+  if (a.stats_partial) return hipErrorInvalidValue;
   const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
   ConvArgs p1 = a, p2 = a;
   p1.in_pix_bytes = p2.in_pix_bytes = (int)(128 * es);
   p1.in_ch_off_bytes = 0;
   p2.in_ch_off_bytes = (int)(64 * es);
   p1.raw_out = raw_tmp;
-  p1.stats_partial = nullptr;
   p2.acc_in = raw_tmp;
   p2.wpack = a.wpack + (size_t)(a.COUT / 32) * 9 * nkg * 64;
   hipError_t e;
   if (prec == DFA_PREC_BF16) {
     e = launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_RAW, 1>(p1, s);
     if (e != hipSuccess) return e;
-    return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true, false, true>(p2, s);
+    return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true>(p2, s);
   }
   e = launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_RAW, 1, false, true>(p1, s);
   if (e != hipSuccess) return e;
-  return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true, true, true>(p2, s);
+  return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, true, true>(p2, s);
 }
 
 // data gradient of encoder block 4: dz4 [.,.,256] -> de3 [.,.,128]; four 64-channel launches chained through raw_tmp.

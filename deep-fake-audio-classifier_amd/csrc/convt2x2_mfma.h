@@ -25,6 +25,11 @@ struct ConvTArgs {
   float* stats_partial;
 };
 
+__device__ __forceinline__ void convt_st4(bf16_t* p, const float* v) {
+  *(uint2*)p = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+__device__ __forceinline__ void convt_st4(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+
 template <typename T, int CIN, int MSUB, bool STATS = false>
 __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
   constexpr int ES = sizeof(T), KG = 32 / ES, NKG = CIN / KG, PB = CIN * ES, CPP = PB / 16;
@@ -63,20 +68,32 @@ __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
 
   const int nslices = 4 * COUT / 32;
   T* out = (T*)a.out;
+  // The WEIGHTS are the A operand (rows = 32 output channels of the slice), the pixels the columns: a lane owns ONE output pixel and
+  // registers 4 g .. 4 g + 3 hold its channels 8 g + 4 h + (0..3) -- four 8-byte (bf16) / 16-byte (fp32) stores per lane and slice
+  // instead of sixteen 2-byte ones (same products in the same k order: the stored values did not change).
   // STATS: slices wave, wave + 4, ... of one wave all carry the SAME 32 output channels (nslices = 4 COUT / 32 with COUT / 32 in
   // {1, 2, 4} groups: slice s <-> group s % (COUT / 32), and 4 is a multiple of that) at different patch positions: one running
-  // pair per lane
-  float st1 = 0.f, st2 = 0.f;
+  // pair per register
+  float st1[STATS ? 16 : 1], st2[STATS ? 16 : 1];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
+  }
   for (int s = wave; s < nslices; s += 4) {
     uint4 wb[NKG];
     const uint4* wp = a.wpack + (size_t)s * NKG * 64 + lane;
 #pragma unroll
     for (int kg = 0; kg < NKG; ++kg) wb[kg] = wp[kg * 64];
-    const int nglob = s * 32;            // all 32 columns of a slice share the patch position q (COUT % 32 == 0)
+    const int nglob = s * 32;            // all 32 channels of a slice share the patch position q (COUT % 32 == 0)
     const int q = nglob / COUT;
-    const int co = nglob - q * COUT + r;
+    const int cb = nglob - q * COUT;     // first channel of the slice
     const int oshift = (q >> 1) * Wo + (q & 1);
-    const float bv = a.bias[co];
+    float bv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *(const float4*)(a.bias + cb + 8 * g + 4 * h);
+      bv[4 * g] = b4.x; bv[4 * g + 1] = b4.y; bv[4 * g + 2] = b4.z; bv[4 * g + 3] = b4.w;
+    }
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
       f32x16_t acc;
@@ -88,27 +105,46 @@ __global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTArgs a) {
 #pragma unroll
       for (int kg = 0; kg < NKG; ++kg) {
         const uint4 av = *(const uint4*)(base + (((2 * kg + h) ^ sw) << 4));
-        acc = Mma<T>::run(av, wb[kg], acc);
+        acc = Mma<T>::run(wb[kg], av, acc);
       }
+      const int ob = obase[p];
+      if (ob >= 0) {
+        T* o = out + (size_t)(ob + oshift) * COUT + cb + 4 * h;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ob = obase[ms * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
-        if (ob >= 0) {
-          const float v = acc[i] + bv;
-          out[(size_t)(ob + oshift) * COUT + co] = cvt_out<T>((STATS || a.no_relu) ? v : fmaxf(v, 0.f));
-          if (STATS) { st1 += v; st2 = fmaf(v, v, st2); }
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[4 * g + e] + bv[4 * g + e];
+            if (STATS) { st1[4 * g + e] += v[e]; st2[4 * g + e] = fmaf(v[e], v[e], st2[4 * g + e]); }
+            if (!STATS && !a.no_relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          convt_st4(o + 8 * g, v);
         }
       }
     }
   }
   if (STATS) {
-    // lane (r, h): channel group g = wave % (COUT / 32), channel 32 g + r, pixels 4 h + ...: fold the halves, park one pair per
-    // (wave, r), then add the waves of a group in wave order (a fixed order: the records are reproducible)
-    st1 += __shfl_xor(st1, 32, 64);
-    st2 += __shfl_xor(st2, 32, 64);
+    // register i of lane (r, h): channel (i & 3) + 8 (i >> 2) + 4 h of the wave's group, this lane's pixels: add the 32 pixel lanes of
+    // each half, park one pair per (wave, channel), then add the waves of a group in wave order (a fixed order: reproducible records)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        st1[i] += __shfl_xor(st1[i], off, 64);
+        st2[i] += __shfl_xor(st2[i], off, 64);
+      }
+    }
     __syncthreads();                                   // every wave is done with the input tile: its first bytes become the scratch
     float* red = (float*)smem;
-    if (h == 0) { red[(wave * 32 + r) * 2] = st1; red[(wave * 32 + r) * 2 + 1] = st2; }
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
+        red[(wave * 32 + c) * 2] = st1[i];
+        red[(wave * 32 + c) * 2 + 1] = st2[i];
+      }
+    }
     __syncthreads();
     if (tid < COUT) {
       const int ng = COUT / 32, g = tid >> 5, rr = tid & 31;

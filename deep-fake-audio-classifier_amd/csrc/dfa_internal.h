@@ -130,7 +130,7 @@ struct dfa_ctx {
   int cae_enc1_mfma = 1;       // auto-encoder eval forward, bf16 mode: block 1 on the matrix cores (cae_enc1_mfma.hip); 0 = the vector-ALU kernel
   int cae_enc_dma = 1;         // auto-encoder eval forward, bf16 mode: encoder blocks 2-4 stage their input rows by LDS-DMA; 0 = through registers
   int cae_dgrad_mfma = 1;      // auto-encoder training, bf16 mode: ConvTranspose2d data gradients on the bf16 matrix cores writing bf16
-  int cae_conv_stats = 1;      // auto-encoder training: encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (0 = separate pass over z)
+  int cae_conv_stats = 1;      // auto-encoder training: encoder blocks 2-3 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (0 = separate pass over z)
   int cae_bwd_fold = 1;        // auto-encoder training: the decoder's BatchNorm-backward apply pass writes dz patch-major and sums the ConvTranspose2d bias gradient (0 = three passes)
                                // (convt_dgrad_bf16.hip); 0 = the fp32-MFMA GEMM + cast pass of round 2
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches

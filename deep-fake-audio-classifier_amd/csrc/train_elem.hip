@@ -397,16 +397,15 @@ __device__ __forceinline__ void upstream8(const float* demb, const T* da, const 
   } else if (SRC == SRC_DIRECT) {
     ld8<T>(da + (((size_t)b * H + t) * W + f) * C + cg * 8, g);
   } else if (SRC == SRC_POOL22) {
+    // a last odd row / column was not pooled: zero gradient.  The load is unconditional (clamped address) and the factor selects --
+    // under a branch hipcc waits for every outstanding load of the batch before it (s_waitcnt vmcnt(0)): one load in flight
     const int Ho = H >> 1, Wo = W >> 1, to = t >> 1, fo = f >> 1;
-    if (to >= Ho || fo >= Wo) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = 0.f;
-      return;
-    }
+    const float k = (to < Ho && fo < Wo) ? 0.25f : 0.f;
+    const int tc = to < Ho ? to : Ho - 1, fc = fo < Wo ? fo : Wo - 1;
     float d[8];
-    ld8<T>(da + (((size_t)b * Ho + to) * Wo + fo) * C + cg * 8, d);
+    ld8<T>(da + (((size_t)b * Ho + tc) * Wo + fc) * C + cg * 8, d);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.25f * d[j];
+    for (int j = 0; j < 8; ++j) g[j] = k * d[j];
   } else {
     const int Ho = H >> 1, to = t >> 1;
     if (to >= Ho) {

@@ -96,7 +96,7 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *                   0 = through registers (bit-identical)
  *   "cae_dgrad_mfma" 1 (default) = auto-encoder training step in bf16 mode: the three ConvTranspose2d data gradients on the bf16
  *                   matrix cores, bf16 result written in place (convt_dgrad_bf16.hip); 0 = fp32-MFMA GEMM + cast pass
- *   "cae_conv_stats" 1 (default) = auto-encoder training step: encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm batch statistics in the
+ *   "cae_conv_stats" 1 (default) = auto-encoder training step: encoder blocks 2-3 and decoder blocks 1-3 take their BatchNorm batch statistics in the
  *                   convolution's epilogue (fp32 sums of the outputs before they are rounded for storage, as the CNN2D's blocks 2 / 3);
  *                   0 = a separate statistics pass over the stored output
  *   "cae_bwd_fold"  1 (default) = auto-encoder training step: the BatchNorm-backward apply pass of decoder blocks 1-3 writes dz in the

@@ -245,9 +245,9 @@ def cae_train_step_emulated(sd, x, emulate="bf16", stats="epilogue"):
       encoder block 1   fp32 convolution from the bf16 features, z1 never stored (statistics of the unrounded z1); its pooled
                         output e1 and the gradient de1 that arrives for it are stored in bf16;
       encoder 2-4       MFMA convolutions with bf16 weights on bf16 inputs; the pre-BatchNorm output z is STORED in bf16; the
-                        batch statistics are the convolution epilogue's fp32 sums of the UNROUNDED outputs (context option
-                        cae_conv_stats = 1, the default; stats="stored" restates the separate pass over the stored tensor of
-                        option 0 and of round 2), the normalisation reads the stored tensor; the BatchNorm backward writes dz in
+                        batch statistics of blocks 2 and 3 are the convolution epilogue's fp32 sums of the UNROUNDED outputs
+                        (context option cae_conv_stats = 1, the default; stats="stored" restates the separate pass over the
+                        stored tensor of option 0 and of round 2 -- which block 4 keeps), the normalisation reads the stored tensor; the BatchNorm backward writes dz in
                         bf16; pooled outputs e and their gradients de in bf16;
       decoder 1-3       ConvTranspose2d(k2, s2) with bf16 weights, zd / dzd / d / dd stored in bf16, statistics as in the encoder;
       decoder 4         fp32 from the bf16 d3.
@@ -286,7 +286,7 @@ def cae_train_step_emulated(sd, x, emulate="bf16", stats="epilogue"):
     h = store(F.avg_pool2d(F.relu(bn(F.conv2d(h, P["encoder.0.weight"], P["encoder.0.bias"], padding=1), "encoder.1")), 2))
     for c, b in ((4, 5), (8, 9), (12, 13)):
         zu = F.conv2d(h, wq(f"encoder.{c}.weight"), P[f"encoder.{c}.bias"], padding=1)
-        h = store(F.avg_pool2d(F.relu(bn(stored(zu), f"encoder.{b}", zu)), 2))
+        h = store(F.avg_pool2d(F.relu(bn(stored(zu), f"encoder.{b}", zu if c != 12 else None)), 2))
     d = h
     for c, b, opad in ((0, 1, (0, 0)), (3, 4, (0, 1)), (6, 7, (0, 0))):
         zu = F.conv_transpose2d(d, wq(f"decoder.{c}.weight"), P[f"decoder.{c}.bias"], stride=2, output_padding=opad)

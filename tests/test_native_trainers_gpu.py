@@ -169,7 +169,7 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
       differs by isolated bf16 ulps of the block-1 output, so the loss agrees to 2e-4.
     * dgrad_m16 -- the encoder's 64 -> 32 and 128 -> 64 data gradients on the 16x16x32 kernels of conv_split.hip (one launch each, as
       the CNN2D's) instead of the 32x32x16 forms (the second chained through fp32 partial sums): same products, other summation order.
-    * cae_conv_stats -- encoder blocks 2-4 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (fp32 sums of the outputs before
+    * cae_conv_stats -- encoder blocks 2-3 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (fp32 sums of the outputs before
       they are rounded for storage, as the CNN2D's blocks 2 / 3) instead of a separate pass over the stored bf16 output: mean and
       variance move by the (unbiased) storage rounding averaged over the batch, the loss agrees to 5e-4.
     * cae_bwd_fold -- the decoder's BatchNorm-backward apply pass writes dz patch-major (no pixel-unshuffle pass) and sums the

@@ -415,7 +415,11 @@ def test_cae_bf16_training_gradients_track_the_reference(golden):
                 continue
             scale = max(float(ref[n].abs().max()), 1e-9)
             rel = float((got[n] - emu[n]).abs().max()) / scale
-            assert rel < (tol_dec if n.startswith("decoder") else tol_enc), (n, tuple(x.shape), rel)
+            # block 1 sits behind all seven BatchNorm + ReLU layers: two restatements that differ only in WHERE a layer's statistics are
+            # summed (stats="epilogue" vs "stored") are 0.12 apart there on the 24 x 96 batch (0.05 at encoder.4, 0.02 in the decoder;
+            # tools/gpu_cae_stats_probe.py) -- that is the resolution of this comparison for block 1, so it gets twice the bound
+            first = n.startswith(("encoder.0.", "encoder.1."))
+            assert rel < (tol_dec if n.startswith("decoder") else min(2 * tol_enc, 0.2) if first else tol_enc), (n, tuple(x.shape), rel)
 
 
 def test_train_cae_cli_end_to_end(tmp_path):
