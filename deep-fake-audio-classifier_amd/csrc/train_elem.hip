@@ -255,13 +255,14 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const T* __restrict__
 }
 
 // ---- forward: BN(batch stats) + ReLU + mean over T       z[B][H][W][C] -> emb[B][C][W]
-template <typename T>
+template <typename T, bool MSUM>
 __global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ emb,
                                                             float* __restrict__ msum, int B, int H, int W, int C) {
-  // msum != nullptr: also save, per (b, f, c), the two sums over t that the BatchNorm BACKWARD reduction of this layer needs --
+  // MSUM (a template parameter: as a run-time test inside the t loop it cut the unrolled body into basic blocks and hipcc kept ONE
+  // load in flight per thread -- 3.3 TB/s): also save, per (b, f, c), the two sums over t that the BatchNorm BACKWARD reduction of this layer needs --
   // n = sum_t mask, sx = sum_t mask * xhat (mask and xhat with the backward pass's own formulas) -- as msum[b][f][c][2].
   // With them dbeta = sum_{b,f} g * n and dgamma = sum_{b,f} g * sx (g = demb / H does not depend on t), so the backward
   // never re-reads z for its reduction (bn_bwd_reduce_saved_kernel below).
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       acc[j] += fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
-      if (msum) {
+      if (MSUM) {
         const float xh = (v[j] - mu[j]) * is[j];
         const bool on = fmaf(gm[j], xh, bt[j]) > 0.f;          // bn_bwd_apply_kernel's mask, bit for bit
         cn[j] += on ? 1.f : 0.f;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_relu_meant_kernel(const T* __restrict_
   const float inv_h = 1.0f / (float)H;
 #pragma unroll
   for (int j = 0; j < 8; ++j) emb[((size_t)b * C + cg * 8 + j) * W + f] = acc[j] * inv_h;
-  if (msum) {
+  if (MSUM) {
     float* o = msum + (((size_t)b * W + f) * C + cg * 8) * 2;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) *reinterpret_cast<float4*>(o + 2 * j) = make_float4(cn[j], sx[j], cn[j + 1], sx[j + 1]);
@@ -863,10 +864,10 @@ hipError_t launch_bn_relu_meant(int prec, const void* z, const float* mean, cons
                                 const float* beta, float* emb, int B, int H, int W, int C, hipStream_t s, float* msum) {
   const size_t total = (size_t)B * W * (C / 8);
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (prec == DFA_PREC_BF16)
-    hipLaunchKernelGGL(bn_relu_meant_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)z, mean, invstd, gamma, beta, emb, msum, B, H, W, C);
-  else
-    hipLaunchKernelGGL(bn_relu_meant_kernel<float>, grid, block, 0, s, (const float*)z, mean, invstd, gamma, beta, emb, msum, B, H, W, C);
+#define DFA_BRM(TT, MS) hipLaunchKernelGGL((bn_relu_meant_kernel<TT, MS>), grid, block, 0, s, (const TT*)z, mean, invstd, gamma, beta, emb, msum, B, H, W, C)
+  if (prec == DFA_PREC_BF16) { if (msum) DFA_BRM(bf16_t, true); else DFA_BRM(bf16_t, false); }
+  else { if (msum) DFA_BRM(float, true); else DFA_BRM(float, false); }
+#undef DFA_BRM
   return hipGetLastError();
 }
 
