@@ -223,6 +223,7 @@ int dfa_ctx_set_option(dfa_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "cae_dgrad_mfma") == 0) { ctx->cae_dgrad_mfma = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_conv_stats") == 0) { ctx->cae_conv_stats = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_bwd_fold") == 0) { ctx->cae_bwd_fold = value ? 1 : 0; return DFA_OK; }
+  if (strcmp(name, "cae_enc4_wide") == 0) { ctx->cae_enc4_wide = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cae_dec_fused") == 0) { ctx->cae_dec_fused = value ? 1 : 0; return DFA_OK; }
   if (strcmp(name, "cnn1d_train_x3") == 0) { ctx->cnn1d_train_x3 = (value < 0 || value > 3) ? 1 : value; return DFA_OK; }
   if (strcmp(name, "cnn1d_fused") == 0) { ctx->cnn1d_fused = value < 0 ? 0 : (value > 2 ? 1 : value); return DFA_OK; }

@@ -8,8 +8,8 @@
 using namespace dfa;
 
 namespace dfa {
-hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s);
-hipError_t launch_cae_dgrad4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
+hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s, int wide);
+hipError_t launch_cae_dgrad4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s, int wide);
 hipError_t launch_train_dgrad3(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s);
 hipError_t launch_train_dgrad2(int prec, const ConvArgs& a, hipStream_t s);
 __global__ void split_sums_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C);
@@ -180,9 +180,14 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
   // ---- weight images (weights move every step)
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[6], p[7], nullptr, nullptr, nullptr, nullptr, 32, 0, 32, 64, prec, m.tenc[0].wpack, m.tenc[0].bias, s, 0));
   DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[12], p[13], nullptr, nullptr, nullptr, nullptr, 64, 0, 64, 128, prec, m.tenc[1].wpack, m.tenc[1].bias, s, 0));
+  m.train_enc4_wide = (prec == DFA_PREC_BF16 && ctx->cae_enc4_wide) ? 1 : 0;
+  if (m.train_enc4_wide) {   // one 128-input-channel image (the eval forward's layout)
+    DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[18], p[19], nullptr, nullptr, nullptr, nullptr, 128, 0, 128, 256, prec, m.tenc[2].wpack, m.tenc[2].bias, s, 0));
+  } else {
   for (int hlf = 0; hlf < 2; ++hlf)
     DFA_HIP_CHECK(ctx, launch_fold_pack_conv3x3(p[18], p[19], nullptr, nullptr, nullptr, nullptr, 128, 64 * hlf, 64, 256, prec,
                                                 m.tenc[2].wpack + (size_t)hlf * (256 / 32) * 9 * nkg * 64, m.tenc[2].bias, s, 0));
+  }
   // bf16 mode: the 64 -> 32 and 128 -> 64 data gradients on the 16x16x32 kernels of conv_split.hip, one launch each (as the CNN2D's;
   // the 32x32x16 forms ran the first with one channel slice per workgroup -- 0.31 ms -- and the second as two launches chained
   // through fp32 partial sums)
@@ -195,8 +200,13 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
   for (int hlf = 0; hlf < 2; ++hlf)
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[12], 64, 128, 64 * hlf, 64, prec, m.tdg[1].wpack + (size_t)hlf * (64 / 32) * 9 * nkg * 64, m.tdg[1].bias, s));
   }
+  if (m.train_enc4_wide) {
+    for (int c = 0; c < 2; ++c)
+      DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[18], 128, 256, 128 * c, 128, prec, m.tdg[2].wpack + (size_t)c * (128 / 32) * 9 * 8 * 64, m.tdg[2].bias, s));
+  } else {
   for (int c = 0; c < 4; ++c)
     DFA_HIP_CHECK(ctx, launch_pack_conv3x3_dgrad(p[18], 128, 256, 64 * c, 64, prec, m.tdg[2].wpack + (size_t)c * (128 / 32) * 9 * nkg * 64, m.tdg[2].bias, s));
+  }
   for (int l = 0; l < 3; ++l) {
     const float* const* q = p + 24 + 6 * l;
     DFA_HIP_CHECK(ctx, launch_fold_pack_convt2x2(q[0], q[1], nullptr, nullptr, nullptr, nullptr, kDCin[l], kDC[l], prec, m.tdec[l].wpack, m.tdec[l].bias, s, 0));
@@ -240,7 +250,7 @@ int dfa_cae_forward_train(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T
     a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l]; a.relu = 0; a.zero_page = ctx->zero_page;
     const bool epi_stats = ctx->cae_conv_stats && l < 3;         // (block 4: conv3x3_inst_cae_train.hip)
     a.stats_partial = epi_stats ? partial : nullptr;             // one [COUT][2] record per (sample, 32-column strip)
-    DFA_HIP_CHECK(ctx, launch_cae_train_fwd(prec, kEC[l - 1], a, (float*)(ws + pl.raw), s));
+    DFA_HIP_CHECK(ctx, launch_cae_train_fwd(prec, kEC[l - 1], a, (float*)(ws + pl.raw), s, m.train_enc4_wide));
     St st = stat_of(ws, pl, l, kEC[l]);
     const size_t npix = (size_t)B * pl.H[l] * pl.W[l];
     int rc = epi_stats ? finalize_records(ctx, partial, B * ((pl.W[l] + 31) / 32), kEC[l], (double)npix, st, rmv(6 * l + 4), rmv(6 * l + 5), momentum)
@@ -381,7 +391,7 @@ int dfa_cae_backward(dfa_ctx* ctx, const void* x, int x_dtype, int B, int T, int
     ConvArgs a{};
     a.in = ws + pl.dz[l]; a.wpack = m.tdg[l - 1].wpack; a.bias = m.tdg[l - 1].bias; a.out = ws + pl.de[l - 1];
     a.B = B; a.H = pl.H[l]; a.W = pl.W[l]; a.COUT = kEC[l - 1]; a.relu = 0; a.zero_page = ctx->zero_page;
-    hipError_t e = (l == 3) ? launch_cae_dgrad4(prec, a, (float*)(ws + pl.raw), s)
+    hipError_t e = (l == 3) ? launch_cae_dgrad4(prec, a, (float*)(ws + pl.raw), s, m.train_enc4_wide)
                  : (l == 2) ? (m.train_dgrad_m16 ? launch_train_dgrad3_m16(a, s, train_conv_variant() != 0) : launch_train_dgrad3(prec, a, (float*)(ws + pl.raw), s))
                             : (m.train_dgrad_m16 ? launch_train_dgrad2_m16(a, s, train_conv_variant() != 0) : launch_train_dgrad2(prec, a, s));
     DFA_HIP_CHECK(ctx, e);

@@ -11,7 +11,7 @@ namespace dfa {
 // epilogue's fixed cost (+49 us) was twice the pass over its 118 MB output.
 hipError_t launch_train_fwd2(int prec, const ConvArgs& a, hipStream_t s);
 hipError_t launch_train_fwd3(int prec, const ConvArgs& a, hipStream_t s);
-hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
+hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw_tmp, hipStream_t s, int wide) {
   const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
   if (cin == 32) {
     if (a.stats_partial) return launch_train_fwd2(prec, a, s);
@@ -23,8 +23,11 @@ hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw
     if (prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 64, 4, 1, 1, 1, EPI_PLAIN, 1>(a, s);
     return launch_conv3x3<float, 64, 4, 1, 1, 1, EPI_PLAIN, 1, false, true>(a, s);
   }
-  // cin == 128: two 64-channel halves; a.wpack holds the two images back to back
   if (a.stats_partial) return hipErrorInvalidValue;
+  // cin == 128, bf16, wide: ONE launch with the 288-register weight slice (one wave per SIMD, LDS-DMA staging: no spill), as the eval
+  // forward's block 4; a.wpack is then ONE [COUT/32][9][8][64] image
+  if (wide && prec == DFA_PREC_BF16) return launch_conv3x3<bf16_t, 128, 4, 1, 1, 1, EPI_PLAIN, 1, false, true>(a, s);
+  // otherwise two 64-channel halves chained through fp32 partial sums; a.wpack holds the two images back to back
   const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
   ConvArgs p1 = a, p2 = a;
   p1.in_pix_bytes = p2.in_pix_bytes = (int)(128 * es);
@@ -46,9 +49,22 @@ hipError_t launch_cae_train_fwd(int prec, int cin, const ConvArgs& a, float* raw
 
 // data gradient of encoder block 4: dz4 [.,.,256] -> de3 [.,.,128]; four 64-channel launches chained through raw_tmp.
 // a.wpack: four [128/32][9][64/KG][64] images (channel windows 0-63, 64-127, 128-191, 192-255 of the 256 inputs)
-hipError_t launch_cae_dgrad4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s) {
+// wide (bf16): TWO 128-channel launches (a.wpack: two [128/32][9][8][64] images, channel windows 0-127, 128-255)
+hipError_t launch_cae_dgrad4(int prec, const ConvArgs& a, float* raw_tmp, hipStream_t s, int wide) {
   const size_t es = (prec == DFA_PREC_BF16) ? 2 : 4;
   const int nkg = (prec == DFA_PREC_BF16) ? 4 : 8;
+  if (wide && prec == DFA_PREC_BF16) {
+    ConvArgs p1 = a, p2 = a;
+    p1.in_pix_bytes = p2.in_pix_bytes = 256 * 2;
+    p1.in_ch_off_bytes = 0;
+    p2.in_ch_off_bytes = 128 * 2;
+    p1.raw_out = raw_tmp;
+    p2.acc_in = raw_tmp;
+    p2.wpack = a.wpack + (size_t)(128 / 32) * 9 * 8 * 64;
+    hipError_t e = launch_conv3x3<bf16_t, 128, 4, 1, 1, 1, EPI_RAW, 1, false, true>(p1, s);
+    if (e != hipSuccess) return e;
+    return launch_conv3x3<bf16_t, 128, 4, 1, 1, 1, EPI_PLAIN, 1, true, true>(p2, s);
+  }
   const size_t img = (size_t)(128 / 32) * 9 * nkg * 64;
   for (int c = 0; c < 4; ++c) {
     ConvArgs p = a;

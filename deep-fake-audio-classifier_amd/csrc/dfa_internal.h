@@ -108,6 +108,7 @@ struct CaeState {
   float *tw1 = nullptr, *tb1 = nullptr;
   int train_c1_mfma = 0;       // this step's block-1 passes run on the matrix cores (train_conv1_mfma.hip, 2x2-pool backward)
   int train_dgrad_m16 = 0;     // this step's 64 -> 32 and 128 -> 64 data-gradient images are in the 16x16x32 order of conv_split.hip (bf16 mode)
+  int train_enc4_wide = 0;     // this step's block-4 forward / data-gradient images are 128-input-channel ones (bf16 mode, option cae_enc4_wide)
   PackedConv tenc[3], tdg[3], tdec[3];
   int train_prec = -1, train_B = 0, train_T = 0;
 };
@@ -132,6 +133,7 @@ struct dfa_ctx {
   int cae_dgrad_mfma = 1;      // auto-encoder training, bf16 mode: ConvTranspose2d data gradients on the bf16 matrix cores writing bf16
   int cae_conv_stats = 1;      // auto-encoder training: encoder blocks 2-3 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (0 = separate pass over z)
   int cae_bwd_fold = 1;        // auto-encoder training: the decoder's BatchNorm-backward apply pass writes dz patch-major and sums the ConvTranspose2d bias gradient (0 = three passes)
+  int cae_enc4_wide = 1;       // auto-encoder training, bf16 mode: encoder block 4 forward in ONE 128-input-channel launch, its data gradient in two (0 = 64-channel launches chained through fp32 partial sums)
                                // (convt_dgrad_bf16.hip); 0 = the fp32-MFMA GEMM + cast pass of round 2
   int cae_dec_fused = 1;       // auto-encoder eval forward, bf16 mode: decoder + squared error as ONE kernel (cae_dec_fused.hip); 0 = four launches
   int cnn1d_train_x3 = 1;      // CNN1D training convolutions (3 forward, 2 data gradients) on the matrix-core layer kernel (conv1d_x3_kernel) where

@@ -102,6 +102,9 @@ int dfa_ctx_set_stream(dfa_ctx* ctx, void* hip_stream);
  *   "cae_bwd_fold"  1 (default) = auto-encoder training step: the BatchNorm-backward apply pass of decoder blocks 1-3 writes dz in the
  *                   patch-major order the ConvTranspose2d gradient GEMMs read and sums the bias gradient on the way; 0 = apply pass,
  *                   channel-sum pass and pixel-unshuffle pass (same values)
+ *   "cae_enc4_wide" 1 (default) = auto-encoder training step in bf16 mode: encoder block 4 (128 -> 256) forward as ONE launch over all 128
+ *                   input channels and its data gradient as two 128-channel launches; 0 = two / four 64-channel launches chained
+ *                   through fp32 partial sums (same products, other summation order)
  *   "cae_dec_fused" 1 (default) = auto-encoder eval forward in bf16 mode: the four decoder blocks, the zero time padding and the
  *                   per-sample squared error run as ONE kernel with the intermediates in LDS / registers; 0 = four launches
  *   "cnn1d_fused"   1 (default) = CNN1D eval forward as ONE kernel for T <= 384 (all three Conv1d layers on the matrix cores with the

@@ -156,7 +156,7 @@ def test_flat_trainer_bridge_writes_gradients_straight_into_the_flat_buffer(gold
     assert first.grad is not None and torch.isfinite(first.grad).all()
 
 
-@pytest.mark.parametrize("option", ["cae_dgrad_mfma", "conv1_mfma", "dgrad_m16", "cae_conv_stats", "cae_bwd_fold"])
+@pytest.mark.parametrize("option", ["cae_dgrad_mfma", "conv1_mfma", "dgrad_m16", "cae_conv_stats", "cae_bwd_fold", "cae_enc4_wide"])
 @pytest.mark.parametrize("B,T,F", [(3, 96, 180), (2, 321, 180), (5, 48, 36)])
 def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, option):
     """Round 3, auto-encoder training step in bf16 mode (autograd of src/model_cae.py:40-79 inside loss.backward(),
@@ -172,6 +172,9 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
     * cae_conv_stats -- encoder blocks 2-3 and decoder blocks 1-3 take their BatchNorm statistics in the convolution's epilogue (fp32 sums of the outputs before
       they are rounded for storage, as the CNN2D's blocks 2 / 3) instead of a separate pass over the stored bf16 output: mean and
       variance move by the (unbiased) storage rounding averaged over the batch, the loss agrees to 5e-4.
+    * cae_enc4_wide -- encoder block 4 (128 -> 256) forward in one launch over all 128 input channels and its data gradient in two
+      128-channel launches, instead of two / four 64-channel launches chained through fp32 partial sums: the same products in
+      another summation order (the forward's output moves by isolated bf16 ulps, so it is held like the other forward-changing options).
     * cae_bwd_fold -- the decoder's BatchNorm-backward apply pass writes dz patch-major (no pixel-unshuffle pass) and sums the
       ConvTranspose2d bias gradient on the way (no channel-sum pass): the same dz values, so every gradient is bit-identical except
       those bias gradients (zero up to rounding; another summation order).
@@ -204,7 +207,7 @@ def test_cae_training_matrix_core_kernels_match_their_round2_twins(B, T, F, opti
                 assert torch.equal(stats[1][n], b0), n
             # (the decoder's layers also see the encoder's re-rounded output)
             assert float((stats[1][n] - b0).abs().max()) <= (1e-4 if n.startswith("encoder.") else 3e-4) * max(float(b0.abs().max()), 1.0), n
-    forward_changes = option in ("conv1_mfma", "cae_conv_stats")
+    forward_changes = option in ("conv1_mfma", "cae_conv_stats", "cae_enc4_wide")
     if option in ("cae_dgrad_mfma", "dgrad_m16", "cae_bwd_fold"):
         assert res[0][0] == res[1][0]
     else:
