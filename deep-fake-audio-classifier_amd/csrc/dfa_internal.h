@@ -382,7 +382,7 @@ hipError_t launch_train_dgrad3_m16(const ConvArgs& a, hipStream_t s, int pipe = 
 hipError_t launch_train_dgrad2_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_cnn2d_block3_m16(const ConvArgs& a, hipStream_t s, int pipe = 1);
 hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
-                                      int ci_off, int co_off, float* dw, float* db, hipStream_t s);
+                                      int ci_off, int co_off, float* dw, float* db, hipStream_t s, int perm = 0);
 void set_train_conv_variant(int v);
 int train_conv_variant();   // conv3x3_inst_train.hip (process-wide test hook)
 void set_wgrad_variant(int v);   // wgrad_mfma.hip: bf16 weight-gradient kernel selection (process-wide test hook)

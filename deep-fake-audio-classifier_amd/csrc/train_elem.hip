@@ -118,7 +118,7 @@ __global__ void reduce_wgrad_window_kernel(const float* __restrict__ partial, in
 // 64 elements x 4 groups of partial records per block; fp64 sums, combined in a fixed order.
 __global__ __launch_bounds__(256) void reduce_wgrad_record_kernel(const float* __restrict__ partial, int nparts, int stride,
                                                                   int cin, int cout, int cin_total, int ci_off, int co_off,
-                                                                  float* __restrict__ dw, float* __restrict__ db) {
+                                                                  float* __restrict__ dw, float* __restrict__ db, int perm) {
   __shared__ double red[4][64];
   const int lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const int n = cout * cin * 9, total = n + cout;
@@ -135,7 +135,16 @@ __global__ __launch_bounds__(256) void reduce_wgrad_record_kernel(const float* _
   if (pg != 0 || e >= total) return;
   const float v = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
   if (e < n) {
-    const int tap = e % 9, ci = (e / 9) % cin, co = e / (9 * cin);
+    int tap, ci, co;
+    if (perm) {   // accumulator-order record of wgrad3x3_bf16_v3_kernel: [tap][g][wave = is + IS cs][lane = 32 h + r][e4]
+      const int IS = cin >> 5, nwr = IS * (cout >> 5);
+      const int e4 = e & 3, ln = (e >> 2) & 63, w = (e >> 8) % nwr, tg = (e >> 8) / nwr;
+      tap = tg >> 2;
+      co = (w / IS) * 32 + e4 + 8 * (tg & 3) + 4 * (ln >> 5);
+      ci = (w % IS) * 32 + (ln & 31);
+    } else {
+      tap = e % 9; ci = (e / 9) % cin; co = e / (9 * cin);
+    }
     dw[((size_t)(co_off + co) * cin_total + ci_off + ci) * 9 + tap] = v;
   } else if (db) {
     db[co_off + e - n] = v;
@@ -809,10 +818,10 @@ hipError_t launch_reduce_wgrad_window(const float* partial, int nparts, int stri
 }
 
 hipError_t launch_reduce_wgrad_record(const float* partial, int nparts, int stride, int cin, int cout, int cin_total,
-                                      int ci_off, int co_off, float* dw, float* db, hipStream_t s) {
+                                      int ci_off, int co_off, float* dw, float* db, hipStream_t s, int perm) {
   const int total = cout * cin * 9 + cout;
   hipLaunchKernelGGL(reduce_wgrad_record_kernel, dim3((total + 63) / 64), dim3(256), 0, s, partial, nparts, stride, cin, cout,
-                     cin_total, ci_off, co_off, dw, db);
+                     cin_total, ci_off, co_off, dw, db, perm);
   return hipGetLastError();
 }
 

@@ -578,15 +578,19 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_bf16_v3_kernel(const bf16_t* 
   }
 #endif
 
+  // The record is written in ACCUMULATOR order, [tap][g][wave of the record][lane][4]: one 16-byte store per lane and register quad,
+  // 1 KiB contiguous per wave instruction (dW order [co][ci][tap] meant 4-byte stores 36 bytes apart: 144 scattered store
+  // instructions per wave, ~30 us of every launch); reduce_wgrad_record_kernel (perm = 1) undoes the permutation while it sums.
   constexpr size_t REC = (size_t)COUT * CIN * 9 + COUT;
+  constexpr int NWR = IS * CS;
   float* out = partial + ((size_t)blockIdx.x * KS + kg) * REC;
+  const int wrec = is + IS * cs;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int co = cs * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, ci = is * 32 + r;
-      out[((size_t)co * CIN + ci) * 9 + tap] = acc[tap][i];
-    }
+    for (int g = 0; g < 4; ++g)
+      *(float4*)(out + ((size_t)((tap * 4 + g) * NWR + wrec) * 64 + lane) * 4) =
+          make_float4(acc[tap][4 * g], acc[tap][4 * g + 1], acc[tap][4 * g + 2], acc[tap][4 * g + 3]);
   if (is == 0) {
     const float v = dbsum + __shfl_xor(dbsum, 32, 64);
     if (h == 0) out[(size_t)COUT * CIN * 9 + cs * 32 + r] = v;
@@ -698,7 +702,8 @@ hipError_t launch_wgrad3x3_window(int prec, int cin, int cout, int cin_total, in
   if (e != hipSuccess) return e;
   const int n = cout * cin * 9;
   // weight block: partial record [cout][cin][9] -> dw rows co_off.., columns ci_off.. of [cout_total][cin_total][9]
-  return launch_reduce_wgrad_record(partial, nparts, n + cout, cin, cout, cin_total, ci_off, co_off, dw, db, s);
+  const int perm = (prec == DFA_PREC_BF16 && wgrad_variant() != 2) ? 1 : 0;   // the v3 kernels write accumulator-order records
+  return launch_reduce_wgrad_record(partial, nparts, n + cout, cin, cout, cin_total, ci_off, co_off, dw, db, s, perm);
 }
 
 }  // namespace dfa
