@@ -104,12 +104,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16_t* __restr
   }
   // acc[c][i]: n = n0 + (2*np + c)*32 + (i&3) + 8*(i>>2) + 4*h,  m = m0 + mt*32 + r
   float* out = partial + (size_t)part * M * N;
+  // (registers 4 g .. 4 g + 3 are four consecutive n: one 16-byte store each)
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int nn = n0 + (2 * np + c) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, mm = m0 + mt * 32 + r;
-      out[(size_t)mm * N + nn] = acc[c][i];
+    for (int g = 0; g < 4; ++g) {
+      const int nn = n0 + (2 * np + c) * 32 + 8 * g + 4 * h, mm = m0 + mt * 32 + r;
+      *(float4*)(out + (size_t)mm * N + nn) = make_float4(acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]);
     }
 }
 
