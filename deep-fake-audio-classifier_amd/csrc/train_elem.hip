@@ -373,12 +373,14 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
   }
   float s = 0.f;
   if (j < K) {
-    const float wj = w[j];
-    const int jt = (tc > 0) ? (j % tw) * tc + j / tw : j;
+    // the thread writes demb at OUTPUT position j (consecutive lanes, consecutive addresses) and fetches the weight that belongs
+    // there once: position j = f * tc + c holds w[c * tw + f].  (Writing input column j's value at its transposed place put every
+    // lane's 4 bytes 4 * tc bytes from its neighbour's: 23.6 MB of single-word stores, 62 us at B = 256.)
+    const float wt = (tc > 0) ? w[(j % tc) * tw + j / tc] : w[j];
 #pragma unroll 4
     for (int b = bg; b < B; b += 8) {
       const float d = dlogits[b];
-      demb[(size_t)b * K + jt] = d * wj;
+      demb[(size_t)b * K + j] = d * wt;
       s = fmaf(d, emb[(size_t)b * K + j], s);
     }
   }
